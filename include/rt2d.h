@@ -1,0 +1,201 @@
+/*
+ * rt2d.h -- C ABI of librt2d_hip.so: 2D acoustic ray propagation + heatmap binning on MI355X (gfx950).
+ *
+ * The reference (ahernot/ray-tracer) has no FFI: its boundary for this path is the Python class API
+ * (Environment2D / Ray2D / RayPack2D / Simulation2D).  Each entry point below names the reference
+ * routine (file:line under the reference tree) whose work it takes over; the Python mirror in
+ * ray-tracer_amd/ binds them with ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every call returns 0 on success, <0 on error; rt2d_last_error() gives a thread-local message.
+ *   - Pointers documented "device" are device pointers valid on the CURRENT HIP device (the one the
+ *     env handle was created on).  Pointers documented "host" are read during the call only.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Launches are
+ *     asynchronous unless stated otherwise.
+ *   - Nothing here allocates per call except rt2d_env_create and the documented scratch of
+ *     rt2d_heatmap_accumulate (none); callers own every buffer.
+ *
+ * Trajectory layout ("tile layout")
+ *   Rays are grouped in tiles of 64 consecutive rays (one wavefront).  Tile t stores its points
+ *   step-major:  X[tile_off[t] + s*64 + lane]  is point s of ray 64*t + lane, for
+ *   s < n_pts[ray]; slots with s >= n_pts[ray] are unspecified.  tile_off has n_tiles+1 entries
+ *   (element counts, not bytes), tile_off[t+1]-tile_off[t] = 64 * max_lane(n_pts).  A wavefront's
+ *   store of one step is one contiguous 512-byte line per coordinate.
+ */
+#ifndef RT2D_H
+#define RT2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT2D_TILE 64
+
+/* stop codes (reference: ray.py:83,165,194,218,228,253,258) */
+#define RT2D_STOP_NONE          0
+#define RT2D_STOP_EXIT_XMIN     1
+#define RT2D_STOP_EXIT_XMAX     2
+#define RT2D_STOP_EXIT_ZMIN     3
+#define RT2D_STOP_EXIT_ZMAX     4
+#define RT2D_STOP_MAX_REBOUNDS  5
+#define RT2D_STOP_BACKPROP      6
+#define RT2D_STOP_MAX_ITER      7
+#define RT2D_STOP_POWER_CUTOFF  8   /* opt-in extension, see Rt2dParams.power_cutoff */
+
+/* per-ray status */
+#define RT2D_RAY_OK               0
+#define RT2D_RAY_ERR_INTERP      -1  /* slope table queried outside its range: the reference raises
+                                        ValueError from env.dx_floor / env.dx_ceil (environment.py:50-51, ray.py:179,202) */
+#define RT2D_RAY_ERR_REBOUND_LOG -2  /* more rebounds than log slots (only possible with n_rebounds_max = -1) */
+
+/* surfaces in the rebound log (reference: ray.py:185,208) */
+#define RT2D_SURFACE_SEDIMENT 0
+#define RT2D_SURFACE_WATER    1
+
+/* out-of-range policy of a table */
+#define RT2D_OOB_EXTRAPOLATE 0
+#define RT2D_OOB_CLAMP       1
+#define RT2D_OOB_ERROR       2
+
+/* Piecewise polynomial on host memory: piece j covers breaks[j] <= x < breaks[j+1];
+ * order 3: ((c0*d + c1)*d + c2), order 2: (c0*d + c1), d = x - breaks[j], coef[j*order + k]. */
+typedef struct {
+    int32_t order;
+    int32_t n_pieces;
+    int32_t oob;
+    int32_t reserved;
+    const double* breaks;   /* host, n_pieces + 1 */
+    const double* coef;     /* host, n_pieces * order */
+} Rt2dTable;
+
+/* Environment description.  Replaces the interpolant objects built by
+ * PhysicsEnvironment2D.__generate (physics_environment.py:61-86) and Environment2D.__init__
+ * (environment.py:43-53). c and dz_c must share their breaks; absorb[0..5] must share theirs. */
+typedef struct {
+    double range_min[2];
+    double range_max[2];
+    Rt2dTable c;          /* sound speed c(z), quadratic, extrapolating */
+    Rt2dTable dz_c;       /* dc/dz, quadratic, extrapolating */
+    Rt2dTable floor;      /* sea floor z(x), linear, clamped */
+    Rt2dTable ceil;       /* surface z(x), linear, clamped */
+    Rt2dTable dx_floor;   /* floor slope, quadratic, out of range = error */
+    Rt2dTable dx_ceil;    /* surface slope, quadratic, out of range = error */
+    Rt2dTable impedance;  /* Z(z) = rho*c, quadratic, extrapolating */
+    Rt2dTable absorb[6];  /* f1, f2, A2, E1, E2, E3 of the absorption model, quadratic, extrapolating */
+} Rt2dEnvDesc;
+
+typedef struct rt2d_env_s* rt2d_env_t;
+
+/* Propagation parameters (reference: ray.py:123-132 kwargs and preferences.py:6-9 defaults). */
+typedef struct {
+    double  dx_max;          /* default 10.0 */
+    double  dz_max;          /* default 0.1 */
+    int32_t n_steps_max;     /* default 100000 */
+    int32_t n_rebounds_max;  /* default -1 = unbounded */
+    int32_t backprop;        /* default 1 */
+    int32_t has_target;      /* 0/1: when 1, dist_to_target / step_target / T_target are produced */
+    double  target[2];
+    int32_t rebound_cap;     /* slots per ray in the rebound log arrays (>= n_rebounds_max+1 when bounded) */
+    int32_t reserved;
+    double  power_cutoff;    /* <= 0: off (reference behaviour).  > 0: stop the ray at the first point whose
+                                transmittance 10^(G/10) at cutoff_freq falls below it (opt-in, SURVEY trap 2) */
+    double  cutoff_freq;
+} Rt2dParams;
+
+/* Per-ray results of a cast; every pointer is a device array of n rays, any of them may be NULL.
+ * Rebound-log arrays hold rebound_cap * n entries, entry k of ray r at [k*n + r]. */
+typedef struct {
+    int32_t* n_pts;        /* trajectory points incl. the source = Ray2D.steps (ray.py:264) */
+    int32_t* stop_code;    /* RT2D_STOP_* = Ray2D.stop_reason */
+    int32_t* n_rebounds;   /* Ray2D.n_rebounds */
+    int32_t* status;       /* RT2D_RAY_* */
+    double*  range;        /* 4*n: [0*n+r]=min x, [1*n+r]=min z, [2*n+r]=max x, [3*n+r]=max z (ray.py:267-268) */
+    double*  L_end;        /* path length at the last point (ray.py:272) */
+    double*  T_end;        /* travel time at the last point (ray.py:275) */
+    double*  dist_to_target; /* |target.z - z(target.x)| by linear interpolation, NaN if out of range (ray.py:282-287) */
+    int32_t* step_target;  /* first step minimising |x - target.x| (ray.py:278) */
+    double*  T_target;     /* travel time at step_target (ray.py:279) */
+    int32_t* reb_step;     /* rebound log: point index of the rebound, = 'step' (ray.py:185) */
+    uint8_t* reb_surface;  /* RT2D_SURFACE_* */
+    double*  reb_velocity; /* c at the point before the rebound */
+    double*  reb_angle;    /* the reference's 'angle' = cos(grazing), reproduced as is (ray.py:184) */
+    double*  reb_pos_x;    /* point before the rebound */
+    double*  reb_pos_z;
+    double*  margin;       /* smallest distance [m] by which any bound / floor / surface comparison of the loop was
+                              decided; a ray with margin ~ 0 is "knife-edge": its step count depends on the last bits
+                              of the arithmetic (no counterpart in the reference; used to report parity honestly) */
+} Rt2dRayOut;
+
+const char* rt2d_last_error(void);
+int32_t rt2d_version(void);
+
+/* Copies the tables to the current device (hipMalloc + hipMemcpy, synchronous). */
+int32_t rt2d_env_create(const Rt2dEnvDesc* desc, rt2d_env_t* env_out);
+int32_t rt2d_env_destroy(rt2d_env_t env);
+/* c(0), the surface sound speed every ray starts with (reference: ray.py:145). Host query. */
+int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out);
+
+/* Ray2D.propagate main loop for n rays, one lane per ray, no trajectory stored (reference:
+ * ray.py:70-259 plus the scalar parts of the post-pass ray.py:263-287).
+ * angles: device, n casting angles in radians.  src: host, 2 doubles.
+ * init_slope / init_mult: optional device arrays (n) overriding tan(angle) and -(c0/cos(angle))^2
+ * (ray.py:138-146) so a caller can inject host-computed values; NULL = computed on device. */
+int32_t rt2d_cast_count(rt2d_env_t env, const double* angles, int64_t n, const double* src,
+                        const Rt2dParams* params, const double* init_slope, const double* init_mult,
+                        const Rt2dRayOut* out, void* stream);
+
+/* Tile offsets for the trajectory layout from n_pts (device, n) -> tile_off (device, n_tiles+1).
+ * total_out (host, may be NULL) receives tile_off[n_tiles]; when non-NULL the call synchronises the stream. */
+int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int64_t* total_out, void* stream);
+
+/* Same propagation, storing every point (reference: the np.insert at ray.py:192,216,236) in tile layout.
+ * C (device, may be NULL) additionally receives the sound speed at every point (ray.py:273). */
+int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const double* src,
+                        const Rt2dParams* params, const double* init_slope, const double* init_mult,
+                        const Rt2dRayOut* out, const int64_t* tile_off, double* X, double* Z, double* C,
+                        void* stream);
+
+/* Post-pass arrays in tile layout (reference: ray.py:271-275): L and T are cumulative (value 0 at point 0);
+ * dL[s] / dT[s] belong to the segment ending at point s (slot 0 is written as 0). Any output may be NULL. */
+int32_t rt2d_post(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off,
+                  const int32_t* n_pts, int64_t n, double* dL, double* L, double* C, double* dT, double* T,
+                  void* stream);
+
+/* Ray2D.populate_NEW for F frequencies (reference: ray.py:339-369, model_absorption.py:19-46,
+ * model_reflection.py:11-46): cumulative gain in dB at every point.
+ * freqs: device, F values in Hz.  G: device, F * total elements, frequency f at G + f*total, tile layout
+ * (may be NULL).  G_end: device, F*n, gain at the last point of each ray at [f*n + r] (may be NULL). */
+int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off,
+                  const int32_t* n_pts, const Rt2dRayOut* rebounds, int32_t rebound_cap, int64_t n,
+                  const double* freqs, int32_t n_freqs, int64_t total, double* G, double* G_end, void* stream);
+
+/* Distance to a target from stored trajectories (reference: ray.py:282-287). dist: device, n. */
+int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,
+                  const double* target, double* dist, void* stream);
+
+/* Heat-map accumulation (reference: simulation.py:120-131 + functions.py:12-19): for every ray, the
+ * value 10^(G/10)^-0.1 of the LAST point falling in each cell (x//res_x, z//-res_z) is added to H.
+ * The cell arithmetic is the reference's integer arithmetic: trunc toward zero, then floor division, then the
+ * flat index ix*nz + iz (negative flat indices wrap once, as NumPy indexing does).
+ * ray_ids: device, n_sel ray indices to bin (NULL = all n rays; a RayPack may hold a subset of a fan).
+ * G: device, one frequency, tile layout.  res: host, 2 ints (metres per cell in x and z).
+ * shape: host, 2 ints (nx, nz).  H: device, nx*nz doubles row-major [ix*nz + iz], accumulated into
+ * (caller zeroes it).  n_dropped (device int64, may be NULL, caller zeroes it) counts points whose flat index
+ * falls outside [-nx*nz, nx*nz) -- the reference raises IndexError there. */
+int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                const int32_t* n_pts, int64_t n, const int32_t* ray_ids, int64_t n_sel,
+                                const int32_t* res, const int32_t* shape,
+                                double* H, int64_t* n_dropped, void* stream);
+
+/* Heat-map presentation (reference: simulation.py:133-138): out[iz*nx + ix] = min(H/max(H), cutoff)^power.
+ * scratch: device, at least 2 doubles. */
+int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, double reduction_power,
+                              double* out, double* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT2D_H */

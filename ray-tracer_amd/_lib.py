@@ -1,0 +1,114 @@
+"""ctypes binding of librt2d_hip.so (C ABI: include/rt2d.h).
+
+The library is the ONLY compute path of this package: if it is missing, or there is no GPU, the
+calls raise -- there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'librt2d_hip.so')
+SOURCES = [os.path.join(_HERE, 'csrc', 'rt2d_kernels.hip')]
+HEADERS = [os.path.join(_HERE, 'csrc', 'rt2d_device.h'), os.path.join(os.path.dirname(_HERE), 'include', 'rt2d.h')]
+
+STOP_REASONS = [None, 'exit-xmin', 'exit-xmax', 'exit-zmin', 'exit-zmax', 'max-rebounds', 'backprop', 'max-iter',
+                'power-cutoff']
+RAY_OK, RAY_ERR_INTERP, RAY_ERR_REBOUND_LOG = 0, -1, -2
+
+EXPORTS = ['rt2d_last_error', 'rt2d_version', 'rt2d_env_create', 'rt2d_env_destroy', 'rt2d_env_surface_speed',
+           'rt2d_cast_count', 'rt2d_traj_layout', 'rt2d_cast_write', 'rt2d_post', 'rt2d_gain', 'rt2d_dist',
+           'rt2d_heatmap_accumulate', 'rt2d_heatmap_finalize']
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP kernels for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = SOURCES + HEADERS
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',
+           '-o', SO_PATH] + SOURCES
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+class Rt2dTable(C.Structure):
+    _fields_ = [('order', C.c_int32), ('n_pieces', C.c_int32), ('oob', C.c_int32), ('reserved', C.c_int32),
+                ('breaks', C.c_void_p), ('coef', C.c_void_p)]
+
+
+class Rt2dEnvDesc(C.Structure):
+    _fields_ = [('range_min', C.c_double * 2), ('range_max', C.c_double * 2),
+                ('c', Rt2dTable), ('dz_c', Rt2dTable), ('floor', Rt2dTable), ('ceil', Rt2dTable),
+                ('dx_floor', Rt2dTable), ('dx_ceil', Rt2dTable), ('impedance', Rt2dTable),
+                ('absorb', Rt2dTable * 6)]
+
+
+class Rt2dParams(C.Structure):
+    _fields_ = [('dx_max', C.c_double), ('dz_max', C.c_double),
+                ('n_steps_max', C.c_int32), ('n_rebounds_max', C.c_int32),
+                ('backprop', C.c_int32), ('has_target', C.c_int32),
+                ('target', C.c_double * 2),
+                ('rebound_cap', C.c_int32), ('reserved', C.c_int32),
+                ('power_cutoff', C.c_double), ('cutoff_freq', C.c_double)]
+
+
+RAY_OUT_FIELDS = ['n_pts', 'stop_code', 'n_rebounds', 'status', 'range', 'L_end', 'T_end', 'dist_to_target',
+                  'step_target', 'T_target', 'reb_step', 'reb_surface', 'reb_velocity', 'reb_angle', 'reb_pos_x',
+                  'reb_pos_z', 'margin']
+
+
+class Rt2dRayOut(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in RAY_OUT_FIELDS]
+
+
+class Rt2dError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library, failing loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise Rt2dError(f'{SO_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
+    L = C.CDLL(SO_PATH)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    L.rt2d_last_error.restype = C.c_char_p
+    L.rt2d_last_error.argtypes = []
+    L.rt2d_version.restype = i32
+    L.rt2d_version.argtypes = []
+    sig = {
+        'rt2d_env_create': [C.POINTER(Rt2dEnvDesc), C.POINTER(vp)],
+        'rt2d_env_destroy': [vp],
+        'rt2d_env_surface_speed': [vp, C.POINTER(dbl)],
+        'rt2d_cast_count': [vp, vp, i64, C.POINTER(dbl), C.POINTER(Rt2dParams), vp, vp, C.POINTER(Rt2dRayOut), vp],
+        'rt2d_traj_layout': [vp, i64, vp, C.POINTER(i64), vp],
+        'rt2d_cast_write': [vp, vp, i64, C.POINTER(dbl), C.POINTER(Rt2dParams), vp, vp, C.POINTER(Rt2dRayOut),
+                            vp, vp, vp, vp, vp],
+        'rt2d_post': [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp],
+        'rt2d_gain': [vp, vp, vp, vp, vp, C.POINTER(Rt2dRayOut), i32, i64, vp, i32, i64, vp, vp, vp],
+        'rt2d_dist': [vp, vp, vp, vp, i64, C.POINTER(dbl), vp, vp],
+        'rt2d_heatmap_accumulate': [vp, vp, vp, vp, vp, i64, vp, i64, C.POINTER(i32), C.POINTER(i32), vp, vp, vp],
+        'rt2d_heatmap_finalize': [vp, C.POINTER(i32), dbl, dbl, vp, vp, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise Rt2dError(lib().rt2d_last_error().decode())

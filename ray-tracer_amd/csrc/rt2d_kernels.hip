@@ -1,0 +1,919 @@
+// rt2d_kernels.hip -- hand-written gfx950 kernels of the 2D acoustic ray path + their C ABI (include/rt2d.h).
+//
+//   rt2d_cast_kernel      one lane = one ray; the Ray2D.propagate loop (reference ray.py:137-259) with the
+//                         scalar post-pass (ray.py:263-287) folded in; environment tables staged in LDS;
+//                         trajectories stored step-major per 64-ray tile (one 512-B line per wave per step).
+//   rt2d_post_kernel      per-point dL, L, C, dT, T (ray.py:271-275).
+//   rt2d_gain_kernel      Ray2D.populate_NEW for F frequencies (ray.py:339-369), GAIN_FCH frequencies per lane.
+//   rt2d_dist_kernel      distance to target from stored trajectories (ray.py:282-287).
+//   rt2d_heatmap_kernel   Simulation2D.heatmap accumulation (simulation.py:120-131, functions.py:12-19):
+//                         one wave per ray, last-write-wins per cell through an LDS hash, f64 atomics into H.
+//   rt2d_hm_* kernels     normalise / clip / power / transpose (simulation.py:133-138).
+//
+// Compiled with -ffp-contract=off: every expression is evaluated exactly as written, which is what makes the
+// trajectories comparable bit for bit with the CPU oracle (oracle/rt2d_oracle.c).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rt2d.h"
+#include "rt2d_device.h"
+
+// ------------------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_err;
+static int32_t fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+static int32_t fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return -1;
+}
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct rt2d_env_s {
+    DevEnv dev;
+    double* blob;       // device
+    int device;
+    std::vector<double> host_blob;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// stepping
+struct CastArgs {
+    DevEnv env;
+    const double* blob;
+    const double* angles;
+    const double* init_slope;
+    const double* init_mult;
+    int64_t n;
+    double src_x, src_z;
+    Rt2dParams p;
+    Rt2dRayOut out;
+    const int64_t* tile_off;
+    double* X; double* Z; double* C;
+};
+
+__device__ __forceinline__ double rt2d_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
+
+// fit_to_bounds closure (ray.py:84-107)
+__device__ __forceinline__ int rt2d_fit(const DevEnv& e, double x_prev, double& x_new, double z_prev, double& z_new,
+                                        double dx_z, double x_dir) {
+    int out = 0;
+    if (x_new < e.range_min[0]) {
+        x_new = e.range_min[0];
+        z_new = -1 * dx_z * (x_new - x_prev) + z_prev;
+        out = 1;
+    } else if (x_new > e.range_max[0]) {
+        x_new = e.range_max[0];
+        z_new = dx_z * (x_new - x_prev) + z_prev;
+        out = 2;
+    }
+    if (z_new < e.range_min[1]) {
+        z_new = e.range_min[1];
+        x_new = x_dir * (z_new - z_prev) / dx_z + x_prev;
+        out = 3;
+    } else if (z_new > e.range_max[1]) {
+        z_new = e.range_max[1];
+        x_new = x_dir * (z_new - z_prev) / dx_z + x_prev;
+        out = 4;
+    }
+    return out;
+}
+
+__device__ __forceinline__ double rt2d_bound_margin(const DevEnv& e, double x, double z) {
+    return fmin(fmin(fabs(x - e.range_min[0]), fabs(x - e.range_max[0])),
+                fmin(fabs(z - e.range_min[1]), fabs(z - e.range_max[1])));
+}
+
+// Online form of interp1d(X, Z, 'linear') evaluated at the target abscissa (ray.py:282-287): the bracketing
+// points of the x-sorted (stable) trajectory are tracked while the points are produced.
+struct TargetTrack {
+    double lo_x, lo_z, hi_x, hi_z;      // largest x < tx (latest wins ties), smallest x >= tx (earliest wins ties)
+    double m1x, m1z, m2x, m2z;          // the two first points of the stable x-sort (for tx == min x)
+    double best_d, best_T; int best_step; int n_lt;
+    __device__ __forceinline__ void init() {
+        lo_x = -INFINITY; hi_x = INFINITY; lo_z = hi_z = 0.0; m1x = m2x = INFINITY; m1z = m2z = 0.0;
+        best_d = INFINITY; best_T = 0.0; best_step = 0; n_lt = 0;
+    }
+    __device__ __forceinline__ void add(double x, double z, double T, int s, double tx) {
+        if (x < tx) { ++n_lt; if (x >= lo_x) { lo_x = x; lo_z = z; } }
+        else if (x < hi_x) { hi_x = x; hi_z = z; }
+        if (x < m1x) { m2x = m1x; m2z = m1z; m1x = x; m1z = z; }
+        else if (x < m2x) { m2x = x; m2z = z; }
+        double d = fabs(x - tx);
+        if (d < best_d) { best_d = d; best_T = T; best_step = s; }      // np.argmin: first minimum (ray.py:278)
+    }
+    __device__ __forceinline__ double dist(double tx, double tz, int n_pts, double min_x, double max_x) const {
+        if (n_pts < 2 || !(tx >= min_x && tx <= max_x)) return __builtin_nan("");
+        double x_lo, z_lo, x_hi, z_hi;
+        if (n_lt == 0) { x_lo = m1x; z_lo = m1z; x_hi = m2x; z_hi = m2z; }
+        else { x_lo = lo_x; z_lo = lo_z; x_hi = hi_x; z_hi = hi_z; }
+        double slope = (z_hi - z_lo) / (x_hi - x_lo);
+        double zt = slope * (tx - x_lo) + z_lo;
+        return fabs(tz - zt);
+    }
+};
+
+template <bool WRITE, bool LDS_TABLES>
+__global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    const double* tab;
+    if (LDS_TABLES) {
+        for (int i = threadIdx.x; i < a.env.step_doubles; i += blockDim.x) s_tab[i] = a.blob[i];
+        __syncthreads();
+        tab = s_tab;
+    } else {
+        tab = a.blob;
+    }
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const DevEnv& e = a.env;
+    const Rt2dParams& p = a.p;
+    const int64_t n = a.n;
+
+    int64_t base = 0;
+    if (WRITE) base = a.tile_off[r >> 6] + (r & 63);
+
+    int status = RT2D_RAY_OK, stop = RT2D_STOP_NONE, n_reb = 0, n_pts = 1;
+    double x = a.src_x, z = a.src_z;
+
+    const double dx_z_max = fabs(p.dz_max / p.dx_max);                    // ray.py:132
+    double c = e.c_surface;                                               // ray.py:145
+    double dx_z, mult;
+    if (a.init_slope) {
+        dx_z = a.init_slope[r];
+        mult = a.init_mult[r];
+    } else {
+        double angle = -1 * a.angles[r] + (M_PI / 2);                     // ray.py:138
+        dx_z = 1 / tan(angle);                                            // ray.py:139
+        double q = c / sin(angle);
+        mult = -1 * (q * q);                                              // ray.py:146
+    }
+    double x_dir = 1.0, kx = x_dir, kz = dx_z;
+
+    // post-pass state (ray.py:263-279)
+    int jz = rt2d_piece(tab, e.cz, z);
+    double c_pt = rt2d_quad_at(tab, e.cz, jz, z - tab[e.cz.off_breaks + jz], 0);   // C[0] = calc_c(z0), ray.py:273
+    double L = 0.0, T = 0.0;
+    double min_x = x, max_x = x, min_z = z, max_z = z;
+    double margin = INFINITY;
+    const bool has_target = p.has_target != 0;
+    const double tx = p.target[0], tz = p.target[1];
+    TargetTrack tt; tt.init();
+    if (has_target) tt.add(x, z, 0.0, 0, tx);
+    if (WRITE) { a.X[base] = x; a.Z[base] = z; if (a.C) a.C[base] = c_pt; }
+
+    for (int i = 0; i < p.n_steps_max; ++i) {
+        // step sizing (ray.py:153-154)
+        if (fabs(dx_z) > dx_z_max) { double s = p.dz_max / fabs(dx_z); kx *= s; kz *= s; }
+        else { kx *= p.dx_max; kz *= p.dx_max; }
+        double x_new = x + kx, z_new = z + kz;                            // ray.py:157
+        margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+
+        {   // horizontal bounds first (ray.py:162-167); the clipped point is NOT appended
+            double xt = x_new, zt = z_new;
+            int out = rt2d_fit(e, x, xt, z, zt, dx_z, x_dir);
+            if (out == 1 || out == 2) { stop = out; break; }
+        }
+
+        const double z_floor = rt2d_eval_lin(tab, e.floor, x_new);        // ray.py:172-173
+        const double z_ceil = rt2d_eval_lin(tab, e.ceil, x_new);
+        margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
+
+        const bool hit_floor = z_new < z_floor;
+        const bool hit_ceil = !hit_floor && (z_new > z_ceil);
+        if (hit_floor || hit_ceil) {                                      // ray.py:176-220
+            const DevTable& surf = hit_floor ? e.floor : e.ceil;
+            const DevTable& slope_t = hit_floor ? e.dx_floor : e.dx_ceil;
+            double fx = rt2d_eval_lin(tab, surf, x);
+            x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
+            z_new = hit_floor ? z_floor : z_ceil;
+            bool ok;
+            double s = rt2d_eval_quad(tab, slope_t, x_new, &ok);
+            if (!ok) { status = RT2D_RAY_ERR_INTERP; break; }
+            double u0 = 1.0, u1 = s;
+            double n0 = hit_floor ? -1 * u1 : u1;
+            double n1 = hit_floor ? u0 : -1 * u0;
+            double ku = kx * u0 + kz * u1, kn = kx * n0 + kz * n1;
+            double rx = ku * u0 - kn * n0, rz = ku * u1 - kn * n1;
+            kx = rx; kz = rz;
+            double q = kz / kx;
+            double ang = 1 / sqrt(1 + q * q);                              // ray.py:184,207 (cos of grazing angle)
+            if (n_reb < p.rebound_cap) {
+                int64_t k = (int64_t)n_reb * n + r;
+                if (a.out.reb_step) a.out.reb_step[k] = i + 1;
+                if (a.out.reb_surface) a.out.reb_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+                if (a.out.reb_velocity) a.out.reb_velocity[k] = c;
+                if (a.out.reb_angle) a.out.reb_angle[k] = ang;
+                if (a.out.reb_pos_x) a.out.reb_pos_x[k] = x;
+                if (a.out.reb_pos_z) a.out.reb_pos_z[k] = z;
+            } else if (a.out.reb_step) {
+                status = RT2D_RAY_ERR_REBOUND_LOG;
+            }
+            n_reb += 1;
+            margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+            if (p.n_rebounds_max > -1 && n_reb > p.n_rebounds_max) {       // ray.py:189-195: the point IS appended
+                rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);
+                double ddx = x_new - x, ddz = z_new - z;
+                double dL = sqrt(ddx * ddx + ddz * ddz);
+                L += dL; T += dL / c_pt;
+                min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
+                min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
+                if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
+                if (WRITE) {
+                    int64_t o = base + (int64_t)n_pts * RT2D_WAVE;
+                    a.X[o] = x_new; a.Z[o] = z_new;
+                    if (a.C) {
+                        int j = rt2d_piece(tab, e.cz, z_new);
+                        a.C[o] = rt2d_quad_at(tab, e.cz, j, z_new - tab[e.cz.off_breaks + j], 0);
+                    }
+                }
+                n_pts += 1;
+                stop = RT2D_STOP_MAX_REBOUNDS;
+                break;
+            }
+        }
+
+        {   // all bounds (ray.py:225-230)
+            double xt = x_new, zt = z_new;
+            int out = rt2d_fit(e, x, xt, z, zt, dx_z, x_dir);
+            if (out) { stop = out; break; }
+        }
+
+        // accept the point (ray.py:235-247)
+        {
+            double ddx = x_new - x, ddz = z_new - z;
+            double dL = sqrt(ddx * ddx + ddz * ddz);                       // ray.py:271
+            L += dL; T += dL / c_pt;                                       // ray.py:272-275
+        }
+        x = x_new; z = z_new;
+        int j = rt2d_piece(tab, e.cz, z);
+        double d = z - tab[e.cz.off_breaks + j];
+        c = rt2d_quad_at(tab, e.cz, j, d, 0);
+        double dz_c = rt2d_quad_at(tab, e.cz, j, d, 1);
+        c_pt = c;
+        min_x = fmin(min_x, x); max_x = fmax(max_x, x);
+        min_z = fmin(min_z, z); max_z = fmax(max_z, z);
+        if (has_target) tt.add(x, z, T, n_pts, tx);
+        if (WRITE) {
+            int64_t o = base + (int64_t)n_pts * RT2D_WAVE;
+            a.X[o] = x; a.Z[o] = z;
+            if (a.C) a.C[o] = c;
+        }
+        n_pts += 1;
+        x_dir = rt2d_sign(kx);
+        dx_z = kz / kx;
+        double dxdx_z = mult * dz_c / (c * c * c);
+        dx_z += dxdx_z * kx;
+        kx = x_dir; kz = dx_z;
+
+        if (!p.backprop && x_dir < 0) { stop = RT2D_STOP_BACKPROP; break; }   // ray.py:252-255
+        if (i == p.n_steps_max - 1) stop = RT2D_STOP_MAX_ITER;                 // ray.py:257-259
+    }
+
+    const Rt2dRayOut& o = a.out;
+    if (o.n_pts) o.n_pts[r] = n_pts;
+    if (o.stop_code) o.stop_code[r] = stop;
+    if (o.n_rebounds) o.n_rebounds[r] = n_reb;
+    if (o.status) o.status[r] = status;
+    if (o.range) { o.range[r] = min_x; o.range[n + r] = min_z; o.range[2 * n + r] = max_x; o.range[3 * n + r] = max_z; }
+    if (o.L_end) o.L_end[r] = L;
+    if (o.T_end) o.T_end[r] = T;
+    if (o.margin) o.margin[r] = margin;
+    if (has_target) {
+        if (o.dist_to_target) o.dist_to_target[r] = tt.dist(tx, tz, n_pts, min_x, max_x);
+        if (o.step_target) o.step_target[r] = tt.best_step;
+        if (o.T_target) o.T_target[r] = tt.best_T;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// trajectory layout: tile_off[t+1] = 64 * max over the tile's lanes of n_pts, then an in-place inclusive scan
+__global__ void rt2d_tile_len_kernel(const int32_t* n_pts, int64_t n, int64_t n_tiles, int64_t* tile_off) {
+    int64_t t = (int64_t)blockIdx.x * (blockDim.x / RT2D_WAVE) + (threadIdx.x / RT2D_WAVE);
+    int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    int64_t r = t * RT2D_WAVE + lane;
+    int v = (r < n) ? n_pts[r] : 0;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    if (lane == 0) tile_off[t + 1] = (int64_t)v * RT2D_WAVE;
+    if (t == 0 && lane == 0) tile_off[0] = 0;
+}
+
+__global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     // one block of 1024
+    __shared__ int64_t s_part[1024];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < n_tiles; start += 1024) {
+        int64_t i = start + threadIdx.x;
+        int64_t v = (i < n_tiles) ? tile_off[i + 1] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int64_t add = (threadIdx.x >= off) ? s_part[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_off[i + 1] = s_part[threadIdx.x] + s_carry;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// post-pass arrays (ray.py:271-275), one lane per ray, coalesced over the tile layout
+struct PostArgs {
+    DevEnv env; const double* blob;
+    const double* X; const double* Z; const int64_t* tile_off; const int32_t* n_pts; int64_t n;
+    double* dL; double* L; double* C; double* dT; double* T;
+};
+
+__global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    const int cz_doubles = a.env.floor.off_breaks;     // the fused c/dz_c table is the blob's first table
+    for (int i = threadIdx.x; i < cz_doubles; i += blockDim.x) s_tab[i] = a.blob[i];
+    __syncthreads();
+    const double* tab = s_tab;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const DevTable& cz = a.env.cz;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+    double xp = a.X[base], zp = a.Z[base];
+    int j = rt2d_piece(tab, cz, zp);
+    double cp = rt2d_quad_at(tab, cz, j, zp - tab[cz.off_breaks + j], 0);
+    double L = 0.0, T = 0.0;
+    if (a.dL) a.dL[base] = 0.0;
+    if (a.L) a.L[base] = 0.0;
+    if (a.C) a.C[base] = cp;
+    if (a.dT) a.dT[base] = 0.0;
+    if (a.T) a.T[base] = 0.0;
+    for (int s = 1; s < np; ++s) {
+        int64_t o = base + (int64_t)s * RT2D_WAVE;
+        double x = a.X[o], z = a.Z[o];
+        double ddx = x - xp, ddz = z - zp;
+        double dL = sqrt(ddx * ddx + ddz * ddz);
+        double dT = dL / cp;
+        L += dL; T += dT;
+        j = rt2d_piece(tab, cz, z);
+        cp = rt2d_quad_at(tab, cz, j, z - tab[cz.off_breaks + j], 0);
+        if (a.dL) a.dL[o] = dL;
+        if (a.L) a.L[o] = L;
+        if (a.C) a.C[o] = cp;
+        if (a.dT) a.dT[o] = dT;
+        if (a.T) a.T[o] = T;
+        xp = x; zp = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gain (ray.py:339-369)
+#define GAIN_FCH 8
+static __constant__ double k_A1 = 0.106, k_A3 = 0.00049;                  // model_absorption.py:34-35
+#define RT2D_WAVE_HEIGHT_RMS 2.0                                          // preferences.py:11
+#define RT2D_DZ_SEDIMENT 2.0                                              // preferences.py:12
+#define RT2D_ZP1 2688000.0                                                // mean of 5 sediments, profile_impedance.py:17-18
+#define RT2D_ZP2 17000000.0                                               // rock, profile_impedance.py:19
+
+__device__ __forceinline__ double rt2d_refcoef_surface(double wavelength, double angle) {   // model_reflection.py:11-18
+    double v = 2 * M_PI / wavelength * RT2D_WAVE_HEIGHT_RMS * sin(angle);
+    return exp(-2 * (v * v));
+}
+
+__device__ __forceinline__ double rt2d_refcoef_sediment(double wavelength, double Zp0) {     // model_reflection.py:21-46
+    double k1 = 2 * M_PI / wavelength;
+    double r01 = (RT2D_ZP1 - Zp0) / (RT2D_ZP1 + Zp0);
+    double r12 = (RT2D_ZP2 - RT2D_ZP1) / (RT2D_ZP2 + RT2D_ZP1);
+    double th = -2 * k1 * RT2D_DZ_SEDIMENT;
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    double er = r12 * cs, ei = r12 * sn;
+    double nr = r01 + er, ni = ei;
+    double dr = 1 + r01 * er, di = r01 * ei;
+    return hypot(nr, ni) / hypot(dr, di);
+}
+
+struct GainArgs {
+    DevEnv env; const double* blob;
+    const double* X; const double* Z; const int64_t* tile_off; const int32_t* n_pts;
+    const int32_t* n_rebounds; const int32_t* reb_step; const uint8_t* reb_surface;
+    const double* reb_velocity; const double* reb_angle; const double* reb_pos_z;
+    int32_t rebound_cap; int64_t n;
+    const double* freqs; int32_t n_freqs; int64_t total;
+    double* G; double* G_end;
+};
+
+__global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
+    __syncthreads();
+    const double* tab = s_tab;                 // gain-section offsets are relative to gain_off
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const int f0 = blockIdx.y * GAIN_FCH;
+    const int nf = min(GAIN_FCH, a.n_freqs - f0);
+    const DevTable& ab = a.env.absorb;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+
+    double fr[GAIN_FCH], ff[GAIN_FCH], S[GAIN_FCH], A[GAIN_FCH];
+#pragma unroll
+    for (int k = 0; k < GAIN_FCH; ++k) {
+        fr[k] = (k < nf) ? a.freqs[f0 + k] : 1.0;
+        double f = fr[k] / 1000;                                           // model_absorption.py:32
+        ff[k] = f * f;
+        S[k] = 0.0; A[k] = 0.0;
+    }
+    const int nreb = min(a.n_rebounds[r], a.rebound_cap);
+    int next_reb = 0;
+    int next_reb_at = (nreb > 0) ? a.reb_step[r] + 1 : 0x7fffffff;         // first point index that carries the loss
+
+    double xp = a.X[base], zp = a.Z[base];
+    if (a.G) {
+#pragma unroll
+        for (int k = 0; k < GAIN_FCH; ++k) if (k < nf) a.G[(int64_t)(f0 + k) * a.total + base] = 0.0;
+    }
+    for (int s = 1; s < np; ++s) {
+        int64_t o = base + (int64_t)s * RT2D_WAVE;
+        double x = a.X[o], z = a.Z[o];
+        double ddx = x - xp, ddz = z - zp;
+        double dL = sqrt(ddx * ddx + ddz * ddz);
+        // six depth factors at the START point of the segment (ray.py:346 uses XZ[:-1, 1])
+        int j = rt2d_piece(tab, ab, zp);
+        double d = zp - tab[ab.off_breaks + j];
+        double f1 = rt2d_quad_at(tab, ab, j, d, 0), f2 = rt2d_quad_at(tab, ab, j, d, 1);
+        double A2 = rt2d_quad_at(tab, ab, j, d, 2), E1 = rt2d_quad_at(tab, ab, j, d, 3);
+        double E2 = rt2d_quad_at(tab, ab, j, d, 4), E3 = rt2d_quad_at(tab, ab, j, d, 5);
+        double f1s = f1 * f1, f2s = f2 * f2;
+        while (s >= next_reb_at) {                                          // ray.py:350-362
+            int64_t kk = (int64_t)next_reb * a.n + r;
+            double vel = a.reb_velocity[kk];
+            bool sediment = a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT;
+            double Zp0 = 0.0, ang = 0.0;
+            if (sediment) Zp0 = rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr);
+            else ang = a.reb_angle[kk];
+#pragma unroll
+            for (int k = 0; k < GAIN_FCH; ++k) {
+                double wavelength = vel / fr[k];
+                double rc = sediment ? rt2d_refcoef_sediment(wavelength, Zp0) : rt2d_refcoef_surface(wavelength, ang);
+                A[k] += 10 * log10(rc);
+            }
+            ++next_reb;
+            next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
+        }
+#pragma unroll
+        for (int k = 0; k < GAIN_FCH; ++k) {
+            double alpha_1 = k_A1 * (f1 * ff[k]) / (f1s + ff[k]);          // model_absorption.py:37-44
+            double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
+            double alpha_3 = k_A3 * ff[k];
+            double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
+            double dG = -1 * alpha / 1000 * dL;                            // ray.py:346
+            S[k] += dG;                                                    // ray.py:347
+            if (a.G && k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = S[k] + A[k];
+        }
+        xp = x; zp = z;
+    }
+    if (a.G_end) {
+#pragma unroll
+        for (int k = 0; k < GAIN_FCH; ++k) if (k < nf) a.G_end[(int64_t)(f0 + k) * a.n + r] = S[k] + A[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// distance to target from stored trajectories (ray.py:282-287)
+__global__ void __launch_bounds__(256) rt2d_dist_kernel(const double* X, const double* Z, const int64_t* tile_off,
+                                                        const int32_t* n_pts, int64_t n, double tx, double tz, double* dist) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int np = n_pts[r];
+    const int64_t base = tile_off[r >> 6] + (r & 63);
+    TargetTrack tt; tt.init();
+    double mn = INFINITY, mx = -INFINITY;
+    for (int s = 0; s < np; ++s) {
+        int64_t o = base + (int64_t)s * RT2D_WAVE;
+        double x = X[o], z = Z[o];
+        mn = fmin(mn, x); mx = fmax(mx, x);
+        tt.add(x, z, 0.0, s, tx);
+    }
+    dist[r] = tt.dist(tx, tz, np, mn, mx);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// heat map accumulation: one wave per ray; LDS hash "cell -> last step in that cell"
+#define HM_EMPTY 0xffffffffffffffffull
+
+__device__ __forceinline__ int64_t rt2d_floordiv(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+
+// flat cell index of a point, or -1 when it falls outside the map (simulation.py:123-125, functions.py:16)
+__device__ __forceinline__ int64_t rt2d_cell(double x, double z, int res_x, int res_z, int64_t nz, int64_t size) {
+    int64_t ix = rt2d_floordiv((int64_t)x, res_x);
+    int64_t iz = rt2d_floordiv((int64_t)z, -1 * (int64_t)res_z);
+    int64_t flat = ix * nz + iz;
+    if (flat < 0) flat += size;
+    if (flat < 0 || flat >= size) return -1;
+    return flat;
+}
+
+__device__ __forceinline__ uint32_t rt2d_hash32(uint32_t k) { k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k; }
+
+struct HeatArgs {
+    const double* X; const double* Z; const double* G; const int64_t* tile_off; const int32_t* n_pts; int64_t n;
+    const int32_t* ray_ids;
+    int32_t res_x, res_z; int64_t nx, nz;
+    double* H; int64_t* n_dropped; int32_t cap;     // cap: hash slots per ray, power of two
+};
+
+__global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
+    const int64_t r = a.ray_ids ? (int64_t)a.ray_ids[blockIdx.x] : (int64_t)blockIdx.x;
+    const int lane = threadIdx.x;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+    const int64_t size = a.nx * a.nz;
+    const uint32_t mask = (uint32_t)a.cap - 1;
+
+    // pass 0: count run ends (candidates) and dropped points
+    int n_cand = 0, n_drop = 0;
+    for (int s = lane; s < np; s += RT2D_WAVE) {
+        int64_t o = base + (int64_t)s * RT2D_WAVE;
+        int64_t cell = rt2d_cell(a.X[o], a.Z[o], a.res_x, a.res_z, a.nz, size);
+        int64_t nxt = -2;
+        if (s + 1 < np) nxt = rt2d_cell(a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.res_x, a.res_z, a.nz, size);
+        if (cell < 0) ++n_drop; else if (nxt != cell) ++n_cand;
+    }
+    for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_xor(n_cand, off); n_drop += __shfl_xor(n_drop, off); }
+    if (lane == 0 && n_drop && a.n_dropped) atomicAdd((unsigned long long*)a.n_dropped, (unsigned long long)n_drop);
+    const int parts = max(1, (4 * n_cand + a.cap - 1) / a.cap);        // expected load <= 1/4 per partition
+
+    for (int part = 0; part < parts; ++part) {
+        for (int i = lane; i < a.cap; i += RT2D_WAVE) s_hash[i] = HM_EMPTY;
+        __syncthreads();
+        // pass A: cell -> max step
+        for (int s = lane; s < np; s += RT2D_WAVE) {
+            int64_t o = base + (int64_t)s * RT2D_WAVE;
+            int64_t cell = rt2d_cell(a.X[o], a.Z[o], a.res_x, a.res_z, a.nz, size);
+            if (cell < 0) continue;
+            if (s + 1 < np && rt2d_cell(a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.res_x, a.res_z, a.nz, size) == cell) continue;
+            uint32_t h = rt2d_hash32((uint32_t)cell);
+            if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
+            unsigned long long packed = ((unsigned long long)(uint32_t)cell << 32) | (uint32_t)s;
+            uint32_t slot = h & mask;
+            for (int probe = 0; probe < a.cap; ++probe) {
+                unsigned long long old = atomicCAS(&s_hash[slot], HM_EMPTY, packed);
+                if (old == HM_EMPTY) break;
+                if ((old >> 32) == (unsigned long long)(uint32_t)cell) { atomicMax(&s_hash[slot], packed); break; }
+                slot = (slot + 1) & mask;
+            }
+        }
+        __syncthreads();
+        // pass B: the step that owns its cell deposits (simulation.py:129-131)
+        for (int s = lane; s < np; s += RT2D_WAVE) {
+            int64_t o = base + (int64_t)s * RT2D_WAVE;
+            int64_t cell = rt2d_cell(a.X[o], a.Z[o], a.res_x, a.res_z, a.nz, size);
+            if (cell < 0) continue;
+            if (s + 1 < np && rt2d_cell(a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.res_x, a.res_z, a.nz, size) == cell) continue;
+            uint32_t h = rt2d_hash32((uint32_t)cell);
+            if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
+            uint32_t slot = h & mask;
+            for (int probe = 0; probe < a.cap; ++probe) {
+                unsigned long long cur = s_hash[slot];
+                if (cur == HM_EMPTY) break;
+                if ((cur >> 32) == (unsigned long long)(uint32_t)cell) {
+                    if ((uint32_t)cur == (uint32_t)s) {
+                        double tmult = pow(10.0, a.G[o] / 10);                 // ray.py:317
+                        double val = pow(tmult, -0.1);                         // simulation.py:129
+                        atomicAdd(&a.H[cell], val);
+                    }
+                    break;
+                }
+                slot = (slot + 1) & mask;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// presentation (simulation.py:133-138)
+__global__ void rt2d_hm_max_kernel(const double* H, int64_t size, unsigned long long* scratch) {
+    // scratch[0]: bit pattern of max over non-negative values; scratch[1]: NaN flag
+    double m = 0.0; bool nan = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = H[i];
+        if (v != v) nan = true; else m = fmax(m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); nan = nan || __shfl_xor((int)nan, off); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&scratch[0], (unsigned long long)__double_as_longlong(m));
+        if (nan) atomicMax(&scratch[1], 1ull);
+    }
+}
+
+__global__ void rt2d_hm_finalize_kernel(const double* H, int64_t nx, int64_t nz, double cutoff, double power,
+                                        const unsigned long long* scratch, double* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx * nz) return;
+    double mx = scratch[1] ? __builtin_nan("") : __longlong_as_double((long long)scratch[0]);
+    int64_t ix = i / nz, iz = i % nz;
+    double v = H[i] / mx;
+    if (v > cutoff) v = cutoff;
+    if (power != 1.0) v = pow(v, power);
+    out[iz * nx + ix] = v;
+}
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+const char* rt2d_last_error(void) { return g_err.c_str(); }
+int32_t rt2d_version(void) { return 100; }
+
+static double host_eval_quad0(const std::vector<double>& blob, const DevTable& t, double x) {
+    int j = 0;
+    for (int k = 0; k < t.n_pieces; ++k) if (blob[t.off_breaks + k] <= x) j = k;
+    double d = x - blob[t.off_breaks + j];
+    const double* c = &blob[t.off_coef + (size_t)j * t.stride];
+    return (c[0] * d + c[1]) * d + c[2];
+}
+
+static bool same_breaks(const Rt2dTable& a, const Rt2dTable& b) {
+    if (a.n_pieces != b.n_pieces) return false;
+    return memcmp(a.breaks, b.breaks, sizeof(double) * (a.n_pieces + 1)) == 0;
+}
+
+// appends `count` host tables that share their breaks as one fused device table
+static int32_t pack_table(std::vector<double>& blob, const Rt2dTable* tabs, int count, int order, int rel_to,
+                          DevTable* out, const char* name) {
+    const Rt2dTable& t0 = tabs[0];
+    if (t0.n_pieces < 1 || !t0.breaks || !t0.coef) return fail("table %s is empty", name);
+    for (int k = 0; k < count; ++k) {
+        if (tabs[k].order != order) return fail("table %s: order %d expected, got %d", name, order, tabs[k].order);
+        if (!same_breaks(t0, tabs[k])) return fail("table %s: fused tables must share their breaks", name);
+    }
+    const int n = t0.n_pieces;
+    for (int j = 0; j < n; ++j) if (!(t0.breaks[j + 1] > t0.breaks[j])) return fail("table %s: breaks not increasing", name);
+    if (blob.size() & 1) blob.push_back(0.0);                  // keep every table 16-byte aligned
+    out->off_breaks = (int32_t)blob.size() - rel_to;
+    blob.insert(blob.end(), t0.breaks, t0.breaks + n + 1);
+    if (blob.size() & 1) blob.push_back(0.0);
+    out->off_coef = (int32_t)blob.size() - rel_to;
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < count; ++k)
+            for (int q = 0; q < order; ++q) blob.push_back(tabs[k].coef[(size_t)j * order + q]);
+    out->n_pieces = n;
+    out->stride = order * count;
+    out->oob = t0.oob;
+    out->lo = t0.breaks[0];
+    out->hi = t0.breaks[n];
+    // uniform-grid hint: interior breaks b_j ~ x0 + j*h (the two end pieces of a quadratic table are 1.5 h long)
+    double h, x0;
+    if (n >= 3) { h = (t0.breaks[n - 1] - t0.breaks[1]) / (n - 2); x0 = t0.breaks[1] - h; }
+    else { h = (t0.breaks[n] - t0.breaks[0]) / n; x0 = t0.breaks[0]; }
+    bool uniform = h > 0;
+    for (int j = 1; j < n && uniform; ++j) if (fabs(t0.breaks[j] - (x0 + j * h)) > 0.25 * h) uniform = false;
+    out->uniform = uniform ? 1 : 0;
+    out->x0 = x0;
+    out->inv_h = uniform ? 1.0 / h : 0.0;
+    return 0;
+}
+
+int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
+    if (!d || !env_out) return fail("rt2d_env_create: null argument");
+    rt2d_env_s* env = new rt2d_env_s();
+    DevEnv& e = env->dev;
+    memset(&e, 0, sizeof e);
+    for (int k = 0; k < 2; ++k) { e.range_min[k] = d->range_min[k]; e.range_max[k] = d->range_max[k]; }
+    std::vector<double>& blob = env->host_blob;
+    int32_t rc = 0;
+    Rt2dTable cz[2] = {d->c, d->dz_c};
+    if ((rc = pack_table(blob, cz, 2, 3, 0, &e.cz, "c/dz_c"))) { delete env; return rc; }
+    if ((rc = pack_table(blob, &d->floor, 1, 2, 0, &e.floor, "floor"))) { delete env; return rc; }
+    if ((rc = pack_table(blob, &d->ceil, 1, 2, 0, &e.ceil, "ceil"))) { delete env; return rc; }
+    if ((rc = pack_table(blob, &d->dx_floor, 1, 3, 0, &e.dx_floor, "dx_floor"))) { delete env; return rc; }
+    if ((rc = pack_table(blob, &d->dx_ceil, 1, 3, 0, &e.dx_ceil, "dx_ceil"))) { delete env; return rc; }
+    if (blob.size() & 1) blob.push_back(0.0);
+    e.step_doubles = (int32_t)blob.size();
+    e.gain_off = (int32_t)blob.size();
+    if ((rc = pack_table(blob, &d->impedance, 1, 3, e.gain_off, &e.imp, "impedance"))) { delete env; return rc; }
+    if ((rc = pack_table(blob, d->absorb, 6, 3, e.gain_off, &e.absorb, "absorb"))) { delete env; return rc; }
+    if (blob.size() & 1) blob.push_back(0.0);
+    e.gain_doubles = (int32_t)blob.size() - e.gain_off;
+    e.total_doubles = (int32_t)blob.size();
+    e.c_surface = host_eval_quad0(blob, e.cz, 0.0);
+    if (hipGetDevice(&env->device) != hipSuccess) { delete env; return fail("no HIP device available"); }
+    if (hipMalloc(&env->blob, blob.size() * sizeof(double)) != hipSuccess) { delete env; return fail("hipMalloc of the table blob failed"); }
+    if (hipMemcpy(env->blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(env->blob); delete env; return fail("hipMemcpy of the table blob failed");
+    }
+    *env_out = env;
+    return 0;
+}
+
+int32_t rt2d_env_destroy(rt2d_env_t env) {
+    if (!env) return 0;
+    if (env->blob) (void)hipFree(env->blob);
+    delete env;
+    return 0;
+}
+
+int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out) {
+    if (!env || !c0_out) return fail("rt2d_env_surface_speed: null argument");
+    *c0_out = env->dev.c_surface;
+    return 0;
+}
+
+#define RT2D_LDS_BUDGET (152 * 1024)
+
+extern "C++" {
+template <bool WRITE>
+static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
+    const int64_t n = a.n;
+    const size_t lds = (size_t)env->dev.step_doubles * sizeof(double);
+    const bool in_lds = lds <= RT2D_LDS_BUDGET;
+    int block;
+    if (n <= 64 * 512) block = 64;                  // small fans: one wave per workgroup, spread over all CUs
+    else if (!in_lds || lds <= 36 * 1024) block = 256;
+    else if (lds <= 76 * 1024) block = 512;
+    else block = 1024;                              // one LDS copy of the tables per CU, 16 waves share it
+    const int64_t grid = (n + block - 1) / block;
+    if (grid > 0x7fffffff) return fail("too many rays for one launch");
+    if (in_lds) {
+        auto k = rt2d_cast_kernel<WRITE, true>;
+        HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false>), dim3((unsigned)grid), dim3(block), 0, stream, a);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+}  // extern "C++"
+
+static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* p,
+                          const double* init_slope, const double* init_mult, const Rt2dRayOut* out) {
+    if (!env || !src || !p || !out) return fail("rt2d_cast: null argument");
+    if (n < 0) return fail("rt2d_cast: negative ray count");
+    if (!angles && !(init_slope && init_mult)) return fail("rt2d_cast: angles is null");
+    if ((init_slope == nullptr) != (init_mult == nullptr)) return fail("rt2d_cast: init_slope and init_mult go together");
+    if (!(p->dx_max > 0) || !(p->dz_max > 0)) return fail("rt2d_cast: dx_max and dz_max must be positive");
+    if (p->n_steps_max < 0) return fail("rt2d_cast: negative n_steps_max");
+    if (p->rebound_cap < 0) return fail("rt2d_cast: negative rebound_cap");
+    if (p->n_rebounds_max > -1 && p->rebound_cap < p->n_rebounds_max + 1 && out->reb_step)
+        return fail("rt2d_cast: rebound_cap %d < n_rebounds_max + 1 = %d", p->rebound_cap, p->n_rebounds_max + 1);
+    if (p->power_cutoff > 0) return fail("rt2d_cast: power_cutoff is not implemented in this build");
+    return 0;
+}
+
+static CastArgs make_cast_args(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* p,
+                               const double* init_slope, const double* init_mult, const Rt2dRayOut* out) {
+    CastArgs a;
+    memset(&a, 0, sizeof a);
+    a.env = env->dev; a.blob = env->blob; a.angles = angles; a.init_slope = init_slope; a.init_mult = init_mult;
+    a.n = n; a.src_x = src[0]; a.src_z = src[1]; a.p = *p; a.out = *out;
+    return a;
+}
+
+int32_t rt2d_cast_count(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* params,
+                        const double* init_slope, const double* init_mult, const Rt2dRayOut* out, void* stream) {
+    int32_t rc = check_cast(env, angles, n, src, params, init_slope, init_mult, out);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    CastArgs a = make_cast_args(env, angles, n, src, params, init_slope, init_mult, out);
+    return launch_cast<false>(env, a, (hipStream_t)stream);
+}
+
+int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* params,
+                        const double* init_slope, const double* init_mult, const Rt2dRayOut* out,
+                        const int64_t* tile_off, double* X, double* Z, double* C, void* stream) {
+    int32_t rc = check_cast(env, angles, n, src, params, init_slope, init_mult, out);
+    if (rc) return rc;
+    if (!tile_off || !X || !Z) return fail("rt2d_cast_write: tile_off, X and Z are required");
+    if (n == 0) return 0;
+    CastArgs a = make_cast_args(env, angles, n, src, params, init_slope, init_mult, out);
+    a.tile_off = tile_off; a.X = X; a.Z = Z; a.C = C;
+    return launch_cast<true>(env, a, (hipStream_t)stream);
+}
+
+int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int64_t* total_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!n_pts || !tile_off) return fail("rt2d_traj_layout: null argument");
+    if (n < 0) return fail("rt2d_traj_layout: negative ray count");
+    const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+    if (n_tiles == 0) {
+        HIP_OK(hipMemsetAsync(tile_off, 0, sizeof(int64_t), stream));
+    } else {
+        const int wpb = 4;
+        hipLaunchKernelGGL(rt2d_tile_len_kernel, dim3((unsigned)((n_tiles + wpb - 1) / wpb)), dim3(wpb * RT2D_WAVE), 0, stream,
+                           n_pts, n, n_tiles, tile_off);
+        hipLaunchKernelGGL(rt2d_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, tile_off);
+        HIP_OK(hipGetLastError());
+    }
+    if (total_out) {
+        HIP_OK(hipMemcpyAsync(total_out, tile_off + n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+int32_t rt2d_post(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                  int64_t n, double* dL, double* L, double* C, double* dT, double* T, void* stream) {
+    if (!env || !X || !Z || !tile_off || !n_pts) return fail("rt2d_post: null argument");
+    if (n <= 0) return n == 0 ? 0 : fail("rt2d_post: negative ray count");
+    PostArgs a; memset(&a, 0, sizeof a);
+    a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts; a.n = n;
+    a.dL = dL; a.L = L; a.C = C; a.dT = dT; a.T = T;
+    const size_t lds = (size_t)env->dev.floor.off_breaks * sizeof(double);
+    if (lds > RT2D_LDS_BUDGET) return fail("rt2d_post: sound-speed table does not fit in LDS");
+    HIP_OK(hipFuncSetAttribute((const void*)rt2d_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int block = (n <= 64 * 512) ? 64 : 256;
+    hipLaunchKernelGGL(rt2d_post_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                  const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, const double* freqs, int32_t n_freqs,
+                  int64_t total, double* G, double* G_end, void* stream) {
+    if (!env || !X || !Z || !tile_off || !n_pts || !reb || !freqs) return fail("rt2d_gain: null argument");
+    if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
+        return fail("rt2d_gain: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
+    if (n < 0 || n_freqs < 0) return fail("rt2d_gain: negative count");
+    if (n == 0 || n_freqs == 0) return 0;
+    GainArgs a; memset(&a, 0, sizeof a);
+    a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts;
+    a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
+    a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
+    a.rebound_cap = rebound_cap; a.n = n; a.freqs = freqs; a.n_freqs = n_freqs; a.total = total; a.G = G; a.G_end = G_end;
+    const size_t lds = (size_t)env->dev.gain_doubles * sizeof(double);
+    if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain: absorption tables do not fit in LDS");
+    HIP_OK(hipFuncSetAttribute((const void*)rt2d_gain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int block = (n <= 64 * 512) ? 64 : 256;
+    dim3 grid((unsigned)((n + block - 1) / block), (unsigned)((n_freqs + GAIN_FCH - 1) / GAIN_FCH));
+    hipLaunchKernelGGL(rt2d_gain_kernel, grid, dim3(block), lds, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,
+                  const double* target, double* dist, void* stream) {
+    if (!X || !Z || !tile_off || !n_pts || !target || !dist) return fail("rt2d_dist: null argument");
+    if (n <= 0) return n == 0 ? 0 : fail("rt2d_dist: negative ray count");
+    const int block = (n <= 64 * 512) ? 64 : 256;
+    hipLaunchKernelGGL(rt2d_dist_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, (hipStream_t)stream,
+                       X, Z, tile_off, n_pts, n, target[0], target[1], dist);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                const int32_t* n_pts, int64_t n, const int32_t* ray_ids, int64_t n_sel,
+                                const int32_t* res, const int32_t* shape,
+                                double* H, int64_t* n_dropped, void* stream) {
+    if (!X || !Z || !G || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
+    if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
+    if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
+    if (shape[0] <= 0 || shape[1] <= 0 || (int64_t)shape[0] * shape[1] >= (1ll << 31)) return fail("rt2d_heatmap_accumulate: bad shape");
+    if (n > 0x7fffffff) return fail("rt2d_heatmap_accumulate: too many rays for one launch");
+    HeatArgs a; memset(&a, 0, sizeof a);
+    a.X = X; a.Z = Z; a.G = G; a.tile_off = tile_off; a.n_pts = n_pts; a.n = n;
+    a.ray_ids = ray_ids;
+    const int64_t n_launch = ray_ids ? n_sel : n;
+    if (n_launch <= 0) return n_launch == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative selection size");
+    a.res_x = res[0]; a.res_z = res[1]; a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
+    a.cap = 4096;
+    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)n_launch), dim3(RT2D_WAVE), (size_t)a.cap * 8, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, double reduction_power,
+                              double* out, double* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!H || !shape || !out || !scratch) return fail("rt2d_heatmap_finalize: null argument");
+    const int64_t nx = shape[0], nz = shape[1], size = nx * nz;
+    if (nx <= 0 || nz <= 0) return fail("rt2d_heatmap_finalize: bad shape");
+    HIP_OK(hipMemsetAsync(scratch, 0, 2 * sizeof(double), stream));
+    const int block = 256;
+    const int64_t blocks = (size + block - 1) / block;
+    hipLaunchKernelGGL(rt2d_hm_max_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(block), 0, stream,
+                       H, size, (unsigned long long*)scratch);
+    hipLaunchKernelGGL(rt2d_hm_finalize_kernel, dim3((unsigned)blocks), dim3(block), 0, stream,
+                       H, nx, nz, cutoff, reduction_power, (const unsigned long long*)scratch, out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,586 @@
+"""Ray fans on the GPU and the reference-shaped views over them.
+
+``RayFan`` is the native form: one batched cast of n rays whose results live in torch tensors on
+the device (per-ray scalars, rebound log, trajectories in 64-ray tile layout, gains).  ``Ray2D`` and
+``RayPack2D`` keep the reference's names, constructor arguments and attributes (ray.py:23-489) and
+are thin, lazy views over a fan, so code written against the reference keeps working:
+
+    ray = Ray2D(env, source, angle, target=target); ray.propagate(dx_max=50, dz_max=25)
+    ray.XZ, ray.T, ray.steps, ray.stop_reason, ray.n_rebounds, ray.dist_to_target, ...
+    ray.populate_NEW(1, 1000.); ray.G[1000.]
+
+Every number comes from the HIP kernels behind include/rt2d.h; there is no CPU fallback.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from .preferences import (DX_MAX_DEFAULT, DZ_MAX_DEFAULT, N_STEPS_MAX, N_REBOUNDS_MAX)
+from . import _lib
+from ._lib import STOP_REASONS, RAY_ERR_INTERP
+
+TILE = 64
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.Rt2dError('no GPU visible to torch: this package computes on MI355X only (no CPU fallback)')
+    return torch
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class RayFan:
+    """n rays cast together.  Device tensors; host copies of the per-ray scalars are made on demand."""
+
+    PROPAGATE_DEFAULTS = dict(backprop=True, dx_max=DX_MAX_DEFAULT, dz_max=DZ_MAX_DEFAULT,
+                              n_steps_max=N_STEPS_MAX, n_rebounds_max=N_REBOUNDS_MAX)
+
+    def __init__(self, env, source, angles, target=None, store=True, device=None, init=None, store_c=False, **kwargs):
+        torch = _torch()
+        self.env = env
+        self.source = np.asarray(source, dtype=np.float64)
+        self.target = None if target is None else np.asarray(target, dtype=np.float64)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.kw = {k: kwargs.get(k, v) for k, v in self.PROPAGATE_DEFAULTS.items()}
+        self.store = bool(store)
+        if torch.is_tensor(angles):
+            self.angles_dev = angles.to(device=self.device, dtype=torch.float64).contiguous()
+            self._angles_host = None
+        else:
+            self._angles_host = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+            self.angles_dev = torch.from_numpy(self._angles_host).to(self.device)
+        self.n = int(self.angles_dev.shape[0])
+        self._host = {}
+        self.G = {}            # freq -> device tensor (total,) in tile layout
+        self.G_end = {}        # freq -> device tensor (n,)
+        self._post = None
+        self._cast(init, store_c)
+
+    # -- casting ----------------------------------------------------------------------------------
+    def _params(self, rebound_cap):
+        p = _lib.Rt2dParams()
+        p.dx_max, p.dz_max = float(self.kw['dx_max']), float(self.kw['dz_max'])
+        p.n_steps_max, p.n_rebounds_max = int(self.kw['n_steps_max']), int(self.kw['n_rebounds_max'])
+        p.backprop = 1 if self.kw['backprop'] else 0
+        p.has_target = 0 if self.target is None else 1
+        if self.target is not None:
+            p.target[:] = [float(self.target[0]), float(self.target[1])]
+        p.rebound_cap = int(rebound_cap)
+        return p
+
+    def _cast(self, init, store_c):
+        torch = _torch()
+        L = _lib.lib()
+        n, dev = self.n, self.device
+        with torch.cuda.device(dev):
+            handle = self.env.device_handle(dev.index)
+            stream = torch.cuda.current_stream().cuda_stream
+            f64 = dict(dtype=torch.float64, device=dev)
+            i32 = dict(dtype=torch.int32, device=dev)
+            self.n_pts = torch.empty(n, **i32)
+            self.stop_code = torch.empty(n, **i32)
+            self.n_rebounds = torch.empty(n, **i32)
+            self.status = torch.empty(n, **i32)
+            self.range = torch.empty((4, n), **f64)
+            self.L_end = torch.empty(n, **f64)
+            self.T_end = torch.empty(n, **f64)
+            self.margin = torch.empty(n, **f64)
+            self.dist = torch.full((n,), float('nan'), **f64)
+            self.step_target = torch.full((n,), -1, **i32)
+            self.T_target = torch.full((n,), float('nan'), **f64)
+            init_slope = init_mult = None
+            if init is not None:
+                init_slope = torch.as_tensor(np.ascontiguousarray(init[0], dtype=np.float64)).to(dev)
+                init_mult = torch.as_tensor(np.ascontiguousarray(init[1], dtype=np.float64)).to(dev)
+            self._init = (init_slope, init_mult)
+            src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
+
+            out = _lib.Rt2dRayOut()
+            out.n_pts, out.stop_code = self.n_pts.data_ptr(), self.stop_code.data_ptr()
+            out.n_rebounds, out.status = self.n_rebounds.data_ptr(), self.status.data_ptr()
+            out.range, out.L_end, out.T_end = self.range.data_ptr(), self.L_end.data_ptr(), self.T_end.data_ptr()
+            out.margin = self.margin.data_ptr()
+            if self.target is not None:
+                out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
+                out.T_target = self.T_target.data_ptr()
+            # pass 1: count points (and rebounds) without storing anything
+            p = self._params(0)
+            _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
+                                         _ptr(init_mult), C.byref(out), stream))
+            self.rebound_cap = 0
+            self.tile_off = self.X = self.Z = self.Cpt = None
+            self.total = 0
+            if not self.store or n == 0:
+                return
+            # layout + pass 2: store trajectories and the rebound log
+            n_tiles = (n + TILE - 1) // TILE
+            self.tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
+            total = C.c_int64(0)
+            _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), C.byref(total), stream))
+            self.total = int(total.value)
+            cap = max(1, int(self.n_rebounds.max().item()))
+            self.rebound_cap = cap
+            self.X = torch.empty(self.total, **f64)
+            self.Z = torch.empty(self.total, **f64)
+            self.Cpt = torch.empty(self.total, **f64) if store_c else None
+            self.reb_step = torch.full((cap, n), -1, **i32)
+            self.reb_surface = torch.zeros((cap, n), dtype=torch.uint8, device=dev)
+            self.reb_velocity = torch.zeros((cap, n), **f64)
+            self.reb_angle = torch.zeros((cap, n), **f64)
+            self.reb_pos_x = torch.zeros((cap, n), **f64)
+            self.reb_pos_z = torch.zeros((cap, n), **f64)
+            out.reb_step, out.reb_surface = self.reb_step.data_ptr(), self.reb_surface.data_ptr()
+            out.reb_velocity, out.reb_angle = self.reb_velocity.data_ptr(), self.reb_angle.data_ptr()
+            out.reb_pos_x, out.reb_pos_z = self.reb_pos_x.data_ptr(), self.reb_pos_z.data_ptr()
+            p = self._params(cap)
+            _lib.check(L.rt2d_cast_write(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
+                                         _ptr(init_mult), C.byref(out), self.tile_off.data_ptr(), self.X.data_ptr(),
+                                         self.Z.data_ptr(), _ptr(self.Cpt), stream))
+            self._out = out
+
+    # -- host copies ------------------------------------------------------------------------------
+    def host(self, name):
+        """NumPy copy of a per-ray tensor (cached)."""
+        h = self._host.get(name)
+        if h is None:
+            h = getattr(self, name).cpu().numpy()
+            self._host[name] = h
+        return h
+
+    @property
+    def angles(self):
+        if self._angles_host is None:
+            self._angles_host = self.angles_dev.cpu().numpy()
+        return self._angles_host
+
+    def ray_steps(self):
+        """Total ray-steps of the fan = appended points, excluding the sources."""
+        return int((self.n_pts.sum() - self.n).item())
+
+    def _need_store(self):
+        if not self.store:
+            raise _lib.Rt2dError('this fan was cast with store=False: trajectories were not kept')
+
+    def ray_slice(self, tensor, i):
+        """Points of ray i out of a tile-layout tensor (a strided device view, no copy)."""
+        self._need_store()
+        base = int(self.host('tile_off')[i // TILE]) + (i % TILE)
+        return tensor[base::TILE][:int(self.host('n_pts')[i])]
+
+    # -- post-pass arrays (ray.py:271-275) --------------------------------------------------------
+    def post(self):
+        if self._post is None:
+            self._need_store()
+            torch = _torch()
+            L = _lib.lib()
+            with torch.cuda.device(self.device):
+                f64 = dict(dtype=torch.float64, device=self.device)
+                d = {k: torch.empty(self.total, **f64) for k in ('dL', 'L', 'C', 'dT', 'T')}
+                _lib.check(L.rt2d_post(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
+                                       self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, d['dL'].data_ptr(),
+                                       d['L'].data_ptr(), d['C'].data_ptr(), d['dT'].data_ptr(), d['T'].data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+            self._post = d
+        return self._post
+
+    # -- gain (ray.py:339-369) --------------------------------------------------------------------
+    def populate(self, *freqs, keep_arrays=True):
+        """Cumulative gain [dB] for every ray at the given frequencies (new ones only)."""
+        self._need_store()
+        torch = _torch()
+        new = [f for f in dict.fromkeys(freqs) if f not in self.G_end]
+        if not new:
+            return
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            f64 = dict(dtype=torch.float64, device=self.device)
+            fr = torch.tensor([float(f) for f in new], **f64)
+            G = torch.empty((len(new), self.total), **f64) if keep_arrays else None
+            G_end = torch.empty((len(new), self.n), **f64)
+            _lib.check(L.rt2d_gain(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
+                                   self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out),
+                                   self.rebound_cap, self.n, fr.data_ptr(), len(new), self.total, _ptr(G),
+                                   G_end.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        for k, f in enumerate(new):
+            if G is not None:
+                self.G[f] = G[k]
+            self.G_end[f] = G_end[k]
+
+    # -- distance to another target (ray.py:282-287) ----------------------------------------------
+    def dist_to(self, target):
+        self._need_store()
+        torch = _torch()
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            out = torch.empty(self.n, dtype=torch.float64, device=self.device)
+            tgt = (C.c_double * 2)(float(target[0]), float(target[1]))
+            _lib.check(L.rt2d_dist(self.X.data_ptr(), self.Z.data_ptr(), self.tile_off.data_ptr(), self.n_pts.data_ptr(),
+                                   self.n, tgt, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out
+
+    # -- heat map (simulation.py:120-131) ---------------------------------------------------------
+    def heatmap_accumulate(self, H, res, shape, freq=1, ray_ids=None, dropped=None):
+        """Adds this fan's rays (or the subset ray_ids, a device int32 tensor) into H (nx*nz, device f64)."""
+        self._need_store()
+        torch = _torch()
+        L = _lib.lib()
+        if freq not in self.G:
+            self.populate(freq)
+        with torch.cuda.device(self.device):
+            res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
+            shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+            n_sel = 0 if ray_ids is None else int(ray_ids.shape[0])
+            _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
+                                                 self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
+                                                 _ptr(ray_ids), n_sel, res_c, shape_c, H.data_ptr(), _ptr(dropped),
+                                                 torch.cuda.current_stream().cuda_stream))
+
+
+class _LinearPath:
+    """calc_z of a ray: interp1d(X, Z, kind='linear', bounds_error=True) semantics (ray.py:282)."""
+
+    def __init__(self, X, Z):
+        order = np.argsort(X, kind='mergesort')
+        self.x, self.y = X[order], Z[order]
+
+    def __call__(self, x_new):
+        x_new = np.asarray(x_new, dtype=np.float64)
+        if np.any(x_new < self.x[0]) or np.any(x_new > self.x[-1]):
+            raise ValueError('A value in x_new is outside the interpolation range.')
+        idx = np.clip(np.searchsorted(self.x, x_new), 1, len(self.x) - 1)
+        lo, hi = idx - 1, idx
+        slope = (self.y[hi] - self.y[lo]) / (self.x[hi] - self.x[lo])
+        return slope * (x_new - self.x[lo]) + self.y[lo]
+
+
+class Ray2D:
+    """One ray.  Same surface as the reference's Ray2D (ray.py:23-405); the numbers come from a RayFan."""
+
+    def __init__(self, env, source, angle, **kwargs):
+        self._propagated = False
+        self.stop_reason = None
+        self.dist_to_target = None
+        self.env = env
+        self.source = source
+        self.target = kwargs.get('target', None)
+        self.angle = angle
+        self._fan, self._i = None, 0
+        self._cache = {}
+        self.freqs = list()
+        self.G = dict()
+        self.Tmult = dict()
+        self.Tmult_target = np.empty((0, 2))
+        self.range_min = np.zeros(2)
+        self.range_max = np.zeros(2)
+        self.steps = 1
+        self.n_rebounds = 0
+
+    @classmethod
+    def _from_fan(cls, fan, i):
+        ray = cls(fan.env, fan.source, float(fan.angles[i]), target=fan.target)
+        ray._bind(fan, i)
+        return ray
+
+    def _bind(self, fan, i):
+        self._fan, self._i = fan, int(i)
+        self._propagated = True
+        self.backprop, self.n_steps_max = fan.kw['backprop'], fan.kw['n_steps_max']
+        self.n_rebounds_max, self.dx_max, self.dz_max = fan.kw['n_rebounds_max'], fan.kw['dx_max'], fan.kw['dz_max']
+        self.status = int(fan.host('status')[i])
+        self.steps = int(fan.host('n_pts')[i])
+        self.stop_reason = STOP_REASONS[int(fan.host('stop_code')[i])]
+        self.n_rebounds = int(fan.host('n_rebounds')[i])
+        rng = fan.host('range')
+        self.range_min = np.array([rng[0, i], rng[1, i]])
+        self.range_max = np.array([rng[2, i], rng[3, i]])
+        self.decision_margin = float(fan.host('margin')[i])
+        if fan.target is not None:
+            self.dist_to_target = np.float64(fan.host('dist')[i])
+            self.step_target = int(fan.host('step_target')[i])
+            self.T_target = np.float64(fan.host('T_target')[i])
+        else:
+            self.step_target = None
+            self.T_target = None
+
+    def __repr__(self):
+        return f'Ray2D ({self.source}, {self.angle})'
+
+    def propagate(self, **kwargs):
+        """Propagate this ray on the GPU (reference: ray.py:70-289).  Raises ValueError where the reference
+        does (slope table left its range, SURVEY trap 6)."""
+        self.verbose = kwargs.get('verbose', False)
+        if self._propagated:
+            if self.verbose:
+                print('Ray2D: ERROR: Ray already propagated')
+            return
+        kw = {k: kwargs[k] for k in RayFan.PROPAGATE_DEFAULTS if k in kwargs}
+        fan = RayFan(self.env, self.source, np.array([self.angle], dtype=np.float64), target=self.target, **kw)
+        self._bind(fan, 0)
+        if self.status == RAY_ERR_INTERP:
+            raise ValueError('A value in x_new is outside the interpolation range.')
+
+    # lazily materialised arrays --------------------------------------------------------------------
+    def _array(self, name, tensor):
+        a = self._cache.get(name)
+        if a is None:
+            a = self._fan.ray_slice(tensor, self._i).cpu().numpy()
+            self._cache[name] = a
+        return a
+
+    @property
+    def XZ(self):
+        if not self._propagated:
+            return np.expand_dims(np.asarray(self.source, dtype=np.float64).copy(), axis=0)
+        xz = self._cache.get('XZ')
+        if xz is None:
+            xz = np.stack((self._array('X', self._fan.X), self._array('Z', self._fan.Z)), axis=1)
+            self._cache['XZ'] = xz
+        return xz
+
+    def _post(self, key):
+        return self._array(key, self._fan.post()[key])
+
+    @property
+    def dL(self):
+        return self._post('dL')[1:]
+
+    @property
+    def L(self):
+        return self._post('L')
+
+    @property
+    def C(self):
+        return self._post('C')
+
+    @property
+    def dT(self):
+        return self._post('dT')[1:]
+
+    @property
+    def T(self):
+        if not self._propagated:
+            return np.array([0., ])
+        return self._post('T')
+
+    @property
+    def calc_z(self):
+        return _LinearPath(self.XZ[:, 0], self.XZ[:, 1])
+
+    @property
+    def rebounds(self):
+        """The rebound log as the reference's list of dicts (ray.py:185,208)."""
+        f, i = self._fan, self._i
+        out = []
+        for k in range(min(self.n_rebounds, f.rebound_cap)):
+            out.append({'step': int(f.host('reb_step')[k, i]),
+                        'surface': 'sediment' if f.host('reb_surface')[k, i] == 0 else 'water-surface',
+                        'velocity': float(f.host('reb_velocity')[k, i]), 'angle': float(f.host('reb_angle')[k, i]),
+                        'position': np.array([f.host('reb_pos_x')[k, i], f.host('reb_pos_z')[k, i]])})
+        return out
+
+    # gain --------------------------------------------------------------------------------------------
+    def populate_NEW(self, *freqs):
+        new = [f for f in freqs if f not in self.freqs]
+        if new:
+            self._fan.populate(*new)
+        for f in new:
+            if f in self.freqs:
+                continue
+            self.G[f] = self._fan.ray_slice(self._fan.G[f], self._i).cpu().numpy()
+            self.freqs.append(f)
+        self.freqs.sort()
+
+    def populate(self, *freqs):
+        """As populate_NEW, plus Tmult = 10^(G/10) (reference: ray.py:291-337; its failure without a target,
+        SURVEY trap 5, is not reproduced)."""
+        self.populate_NEW(*freqs)
+        for f in freqs:
+            if f not in self.Tmult:
+                self.Tmult[f] = np.power(10, self.G[f] / 10)
+                if self.target is not None and len(self.G[f]) > self.step_target:
+                    self.Tmult_target = np.insert(self.Tmult_target, 0, np.array([f, self.Tmult[f][self.step_target]]), axis=0)
+        self.Tmult_target = np.sort(self.Tmult_target, axis=0)
+
+    def closest_step_to_point(self, target):
+        d = np.sqrt(np.power(target[0] - self.XZ[:, 0], 2) + np.power(target[1] - self.XZ[:, 1], 2))
+        return np.argmin(d)
+
+    def point(self, step):
+        return self.XZ[step]
+
+    def gain(self, step):
+        return np.array([self.G[freq][step] for freq in self.freqs])
+
+    def gen_filter(self, target):
+        """Travel time and transmittance at a target near the path (reference: ray.py:382-405)."""
+        step_target = self.closest_step_to_point(target)
+        p = self.point(step_target)
+        d_target = np.linalg.norm(target - p)
+        z_avg = ((target + p) / 2)[1]
+        G_add = -1 * self.env.penv.calc_dl_dG(np.array(self.freqs, dtype=np.float64), z_avg) / 1000 * d_target
+        G_target = self.gain(step_target) + G_add
+        Tmult_target = np.power(10, G_target / 10)
+        T_add = d_target / self.env.penv.calc_c(z_avg)
+        return self.T[step_target] + T_add, Tmult_target
+
+    def plot(self, fig, **kwargs):
+        if self._propagated:
+            import matplotlib.pyplot as plt
+            plt.plot(self.XZ[:, 0], self.XZ[:, 1], figure=fig, **kwargs)
+
+
+class _RayList:
+    """List-like view over the rays of a pack; Ray2D objects are created on access."""
+
+    def __init__(self):
+        self._segments = []      # (fan, index array) or (None, [Ray2D, ...])
+        self._counts = []
+        self._made = {}
+
+    def __len__(self):
+        return int(sum(self._counts))
+
+    def _add_segment(self, fan, idx):
+        self._segments.append((fan, idx))
+        self._counts.append(len(idx))
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        n = len(self)
+        if k < 0:
+            k += n
+        if not 0 <= k < n:
+            raise IndexError(k)
+        ray = self._made.get(k)
+        if ray is None:
+            off = k
+            for (fan, idx), cnt in zip(self._segments, self._counts):
+                if off < cnt:
+                    ray = idx[off] if fan is None else Ray2D._from_fan(fan, int(idx[off]))
+                    break
+                off -= cnt
+            self._made[k] = ray
+        return ray
+
+    def __iter__(self):
+        for k in range(len(self)):
+            yield self[k]
+
+
+class RayPack2D:
+    """Container of rays, one per angle (reference: ray.py:430-489).  Whole fans are added without creating
+    per-ray objects (``add_fan``); ``rays``, ``angles``, ``stop_reasons`` and ``dist`` are built lazily."""
+
+    def __init__(self):
+        self.rays = _RayList()
+        self.freqs = list()
+        self.n_rays, self.n_angles, self.n_freqs = 0, 0, 0
+        self.range_min_plot = np.zeros(2)
+        self.range_max_plot = np.zeros(2)
+        self.size_plot = np.zeros(2)
+        self.dist_sorted = None
+        self._angle_set = set()
+        self._dist_keys = []
+        self._maps = None
+        self.n_failed = 0        # rays whose status was an error and that were therefore not added
+
+    def __repr__(self):
+        return f'Raypack containing {self.n_rays} rays cast with {self.n_angles} angles'
+
+    def _fold_range(self, rmin, rmax):
+        # ray.py:466-472: starts from zeros, so the origin is always inside the plot range
+        self.range_min_plot = np.minimum(self.range_min_plot, rmin)
+        self.range_max_plot = np.maximum(self.range_max_plot, rmax)
+        self.size_plot = self.range_max_plot - self.range_min_plot
+
+    def add_fan(self, fan, indices=None):
+        """Add rays of a fan (all, or the given indices), skipping errored rays and angles already present."""
+        ang = fan.angles
+        status = fan.host('status')
+        idx_all = np.arange(fan.n) if indices is None else np.asarray(indices, dtype=np.int64)
+        keep = []
+        for i in idx_all:
+            a = float(ang[i])
+            if status[i] == RAY_ERR_INTERP:
+                self.n_failed += 1
+                continue
+            if a in self._angle_set:
+                continue
+            self._angle_set.add(a)
+            keep.append(int(i))
+        if not keep:
+            return
+        keep = np.asarray(keep, dtype=np.int64)
+        self.rays._add_segment(fan, keep)
+        self.n_rays += len(keep)
+        self.n_angles += len(keep)
+        rng = fan.host('range')
+        self._fold_range(np.array([rng[0, keep].min(), rng[1, keep].min()]), np.array([rng[2, keep].max(), rng[3, keep].max()]))
+        if fan.target is not None:
+            self._dist_keys.append(fan.host('dist')[keep])
+        else:
+            self._dist_keys.append(np.full(len(keep), np.nan))   # placeholder for dist_to_target = None
+        self._update_dist_sorted()
+        self._maps = None
+
+    def add(self, *rays):
+        for ray in rays:
+            if ray.angle in self._angle_set:
+                continue
+            self._angle_set.add(ray.angle)
+            if ray._fan is not None:
+                self.rays._add_segment(ray._fan, np.array([ray._i], dtype=np.int64))
+                self.rays._made[len(self.rays) - 1] = ray
+            else:
+                self.rays._add_segment(None, [ray])
+            self.n_rays += 1
+            self.n_angles += 1
+            self._fold_range(ray.range_min, ray.range_max)
+            d = ray.dist_to_target
+            self._dist_keys.append(np.array([np.nan if d is None else d], dtype=np.float64))
+        self._update_dist_sorted()
+        self._maps = None
+
+    def _update_dist_sorted(self):
+        if self._dist_keys:
+            self.dist_sorted = np.sort(np.unique(np.concatenate(self._dist_keys)))   # unique keeps a single NaN, like dict keys of one None
+
+    def _build_maps(self):
+        if self._maps is None:
+            angles, stops, dist = {}, {}, {}
+            for ray in self.rays:
+                angles[ray.angle] = ray
+                stops.setdefault(ray.stop_reason, []).append(ray)
+                dist.setdefault(ray.dist_to_target, []).append(ray)
+            self._maps = (angles, stops, dist)
+        return self._maps
+
+    @property
+    def angles(self):
+        return self._build_maps()[0]
+
+    @property
+    def stop_reasons(self):
+        return self._build_maps()[1]
+
+    @property
+    def dist(self):
+        return self._build_maps()[2]
+
+    def segments(self):
+        """[(fan, index array)] of the fan-backed rays, for batched device work."""
+        return [(fan, idx) for fan, idx in self.rays._segments if fan is not None]
+
+    def populate(self, *freqs):
+        for fan, _ in self.segments():
+            fan.populate(*freqs)
+        for f in freqs:
+            if f not in self.freqs:
+                self.freqs.append(f)
+        self.n_freqs = len(self.freqs)

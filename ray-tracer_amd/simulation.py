@@ -1,0 +1,252 @@
+"""Fan orchestration, heat maps and eigenray search on the GPU.
+
+Host-side mirror of the reference's ``Simulation2D`` / ``EigenraySim2D`` (simulation.py:29-314): same
+constructor arguments, ``cast(*angles, pack=, target=, + propagate kwargs)``, ``raypacks``, ``plot`` and the
+restored ``heatmap(resolution=[50, 25], reduction_power=.5, cutoff=.02, pack=)`` whose body the reference
+ships commented out (simulation.py:96-138).  ``cast`` hands the whole angle list to ONE batched device
+cast instead of looping ``for angle in angles`` (simulation.py:89-94).
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from .rays import RayFan, RayPack2D, _torch
+from . import _lib
+
+
+class Simulation2D:
+
+    def __init__(self, env, source, **kwargs):
+        """
+        :param env: Environment2D
+        :param source: source point (x, z)
+        :param kwargs/pack_default: default pack name ('main'; None = create packs by hand)
+        :param kwargs/verbose, verbose_depth, verbose_depth_max: accepted as in the reference
+        """
+        self.verbose = kwargs.get('verbose', False)
+        self.verbose_depth_max = kwargs.get('verbose_depth_max', 0)
+        self.verbose_depth = kwargs.get('verbose_depth', 0)
+        # the reference only sets this under verbose=True and then reads it unconditionally (SURVEY trap 4);
+        # here it is always defined so cast() also works with verbose=False
+        self.verbose_next = self.verbose and ((self.verbose_depth < self.verbose_depth_max) or (self.verbose_depth_max == -1))
+        self._vi = '\t' * self.verbose_depth + self.__class__.__name__ + ': '
+
+        self.env = env
+        self.source = source
+        self.raypacks = dict()
+        self.pack_default = kwargs.get('pack_default', 'main')
+        if self.pack_default:
+            self.raypacks[self.pack_default] = RayPack2D()
+
+        self.range_min = self.env.range_min
+        self.range_max = self.env.range_max
+        self.size = self.env.size
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' object'
+
+    def cast(self, *angles, **kwargs):
+        """Propagate rays at the given angles and add them to a pack (reference: simulation.py:69-94).
+
+        ``angles`` may also be one array.  Propagate kwargs (backprop, dx_max, dz_max, n_steps_max,
+        n_rebounds_max) and ``target`` are forwarded.  ``store=False`` keeps only per-ray scalars
+        (termination, rebounds, distance to target) -- enough for sweeps.  ``strict=True`` raises
+        ValueError if any ray leaves the slope tables, as the reference's loop would.
+        Returns the RayFan.
+        """
+        pack = kwargs.get('pack', self.pack_default)
+        if pack not in self.raypacks:
+            self.raypacks[pack] = RayPack2D()
+        raypack = self.raypacks[pack]
+        if len(angles) == 1 and np.ndim(angles[0]) == 1:
+            angles = angles[0]
+        angles = np.asarray(angles, dtype=np.float64)
+        fan = RayFan(self.env, self.source, angles, target=kwargs.get('target', None), store=kwargs.get('store', True),
+                     **{k: kwargs[k] for k in RayFan.PROPAGATE_DEFAULTS if k in kwargs})
+        if kwargs.get('strict', False) and bool((fan.status == _lib.RAY_ERR_INTERP).any().item()):
+            raise ValueError('A value in x_new is outside the interpolation range.')
+        raypack.add_fan(fan)
+        return fan
+
+    def heatmap_full(self, **kwargs):
+        """Un-normalised heat map (nx, nz) as a device tensor, plus the number of dropped points."""
+        torch = _torch()
+        res = np.asarray(kwargs.get('resolution', np.array([50, 25])))
+        if not np.issubdtype(res.dtype, np.integer):
+            if np.any(res != np.round(res)):
+                raise TypeError('heatmap resolution must be integral (the reference floor-divides integer coordinates)')
+            res = res.astype(np.int64)
+        freq = kwargs.get('freq', 1)
+        raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
+        shape = np.ceil(raypack.size_plot / res).astype(int) + 1         # simulation.py:117
+        segs = raypack.segments()
+        device = segs[0][0].device if segs else torch.device('cuda', torch.cuda.current_device())
+        H = torch.zeros(int(shape[0]) * int(shape[1]), dtype=torch.float64, device=device)
+        dropped = torch.zeros(1, dtype=torch.int64, device=device)
+        for fan, idx in segs:
+            ids = None
+            if len(idx) != fan.n:
+                ids = torch.as_tensor(np.asarray(idx, dtype=np.int32), device=device)
+            fan.heatmap_accumulate(H, res, shape, freq=freq, ray_ids=ids, dropped=dropped)
+        return H.view(int(shape[0]), int(shape[1])), dropped
+
+    def heatmap(self, **kwargs):
+        """Ray-power heat map (reference: commented block simulation.py:96-138).
+
+        :param kwargs/resolution: cell size (x, z) in metres, integers (default [50, 25])
+        :param kwargs/reduction_power: exponent applied after normalisation (default .5)
+        :param kwargs/cutoff: saturation of the normalised map (default .02)
+        :param kwargs/pack: pack name
+        :param kwargs/freq: frequency whose gain weights the rays (default 1, as the reference)
+        :param kwargs/as_tensor: return the device tensor instead of a NumPy array
+        Returns the (nz, nx) map, i.e. ``heatmap_plot.T``.
+        """
+        torch = _torch()
+        H, _ = self.heatmap_full(**kwargs)
+        nx, nz = H.shape
+        out = torch.empty((nz, nx), dtype=torch.float64, device=H.device)
+        scratch = torch.empty(2, dtype=torch.float64, device=H.device)
+        shape_c = (C.c_int32 * 2)(int(nx), int(nz))
+        with torch.cuda.device(H.device):
+            _lib.check(_lib.lib().rt2d_heatmap_finalize(H.data_ptr(), shape_c, float(kwargs.get('cutoff', .02)),
+                                                        float(kwargs.get('reduction_power', .5)), out.data_ptr(),
+                                                        scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out if kwargs.get('as_tensor', False) else out.cpu().numpy()
+
+    def plot(self, fig, **kwargs):
+        pack = kwargs.pop('pack', self.pack_default)
+        for ray in self.raypacks[pack].rays:
+            ray.plot(fig, **kwargs)
+        self.env.plot(fig, c='red')
+
+
+class EigenraySim2D(Simulation2D):
+    """Sweep + refine search of the rays that connect source and target (reference: simulation.py:158-314).
+    The FFT filter synthesis of the reference (get_filter*) is outside this path."""
+
+    _PROP_KEYS = tuple(RayFan.PROPAGATE_DEFAULTS)
+
+    def __init__(self, env, source, target, n_rays, n_rebounds_max, **kwargs):
+        self.init_kwargs = kwargs
+        self.pack_temp_scan = '__iter0-scan'
+        self.pack_scan = 'scan'
+        self.gen_pack_temp_refine = lambda n_refines, ray_id: f'__iter{n_refines}-refine-ray{ray_id}'
+        self.gen_pack_refine = lambda n_refines: f'refine-{n_refines}'
+
+        super(EigenraySim2D, self).__init__(env, source, pack_default=None, **kwargs)
+        self.target = target
+        self.n_rebounds_max = n_rebounds_max
+        self.n_rays = n_rays
+        self.precision_cutoff = kwargs.get('precision_cutoff', 0.1)
+        self.dist = dict()
+        self.dist_avg = None
+        self.n_refines = 0
+        self._angular_precision = None
+
+        self.n_rays_scan = kwargs.get('n_rays_scan', self.n_rays * 10)
+        self._scan(kwargs.get('scan_angle_min', None), kwargs.get('scan_angle_max', None))
+
+    def _prop(self):
+        return {k: self.init_kwargs[k] for k in self._PROP_KEYS if k in self.init_kwargs}
+
+    def _scan(self, angle_min=None, angle_max=None):
+        # aperture from mean depths and the rebound budget (simulation.py:218-228)
+        Dz = abs(self.env.ceil_avg - self.env.floor_avg)
+        Dx = abs(self.target[0] - self.source[0])
+        Dz_sc = abs(self.source[1])
+        Dz_tc = abs(self.target[1])
+        N = self.n_rebounds_max + 1
+        if N % 2 == 0:
+            angle_min = angle_min if angle_min else -1 * np.arcsin(Dx / (N * Dz - Dz_sc + Dz_tc))
+            angle_max = angle_max if angle_max else np.arcsin(Dx / (N * Dz + Dz_sc - Dz_tc))
+        else:
+            angle_min = angle_min if angle_min else -1 * np.arcsin(Dx / ((N + 1) * Dz - Dz_sc - Dz_tc))
+            angle_max = angle_max if angle_max else np.arcsin(Dx / ((N - 1) * Dz + Dz_sc + Dz_tc))
+
+        if self.verbose:
+            print(f'{self._vi}Scanning using {self.n_rays_scan} rays between angles {angle_min} and {angle_max}')
+        self._angular_precision = (angle_max - angle_min) / (self.n_rays_scan - 1)
+
+        # sweep: scalars only, one batched cast (simulation.py:237-238)
+        angles = np.linspace(angle_min, angle_max, self.n_rays_scan)
+        kw = self._prop()
+        kw['n_rebounds_max'] = self.n_rebounds_max
+        torch = _torch()
+        sweep = RayFan(self.env, self.source, angles, target=self.target, store=False, **kw)
+        self.scan_fan = sweep
+        # keep the rays whose distance is among the n_rays smallest distinct distances (simulation.py:241-249):
+        # top-k on the device, ties kept
+        dist = sweep.dist.clone()
+        dist[sweep.status != 0] = float('nan')
+        valid = ~torch.isnan(dist)
+        uniq = torch.unique(dist[valid])                       # sorted ascending
+        if uniq.numel() == 0:
+            raise KeyError('no scanning ray reaches the target abscissa')
+        kth = uniq[min(self.n_rays, uniq.numel()) - 1]
+        sel = torch.nonzero(valid & (dist <= kth)).flatten()
+        sel = sel[torch.argsort(dist[sel], stable=True)]
+        sel_angles = angles[sel.cpu().numpy()]
+        # re-cast the selected rays with trajectories so they are full Ray2D objects
+        self.raypacks[self.pack_scan] = RayPack2D()
+        fan = RayFan(self.env, self.source, sel_angles, target=self.target, store=True, **kw)
+        self.raypacks[self.pack_scan].add_fan(fan)
+        self.pack_default = self.pack_scan
+        self.dist_avg = np.mean(self.raypacks[self.pack_scan].dist_sorted)
+        if self.verbose:
+            print(f'{self._vi}Scan mean distance: {self.dist_avg}')
+
+    def refine(self, **kwargs):
+        """Refine each kept ray inside a cone of +-cone_half_angle (reference: simulation.py:255-314).
+        All cones of one iteration go into ONE batched cast."""
+        cone_half_angle = kwargs.get('cone_half_angle', self._angular_precision)
+        n_rays = kwargs.get('n_rays', 5)
+        iterations = kwargs.get('iterations', 1)
+        force_refine = kwargs.get('force_refine', False)
+        torch = _torch()
+
+        for _ in range(iterations):
+            if self.dist_avg <= self.precision_cutoff and not force_refine:
+                if self.verbose:
+                    print(f'{self._vi}Target precision reached')
+                break
+            raypack_prev = self.raypacks[self.pack_default]
+            self.n_refines += 1
+            pack_refine = self.gen_pack_refine(self.n_refines)
+            self.raypacks[pack_refine] = RayPack2D()
+            raypack_refine = self.raypacks[pack_refine]
+
+            prev = list(raypack_prev.rays)
+            k = len(prev)
+            # note: like the reference (simulation.py:298), refine casts WITHOUT n_rebounds_max
+            cones = np.stack([np.linspace(r.angle - cone_half_angle, r.angle + cone_half_angle, n_rays) for r in prev])
+            fan = RayFan(self.env, self.source, cones.reshape(-1), target=self.target, store=True, **self._prop())
+            dist = fan.dist.clone()
+            dist[fan.status != 0] = float('nan')
+            dist = dist.view(k, n_rays).cpu().numpy()
+            for ray_id, ray in enumerate(prev):
+                # candidates in the reference's order: the cone rays (duplicate angles skipped), then the parent
+                cand_d, cand = [], []
+                seen = set()
+                for j in range(n_rays):
+                    a = float(cones[ray_id, j])
+                    if a in seen:
+                        continue
+                    seen.add(a)
+                    cand_d.append(dist[ray_id, j]); cand.append(j)
+                if ray.angle not in seen:
+                    cand_d.append(np.nan if ray.dist_to_target is None else ray.dist_to_target); cand.append(-1)
+                cand_d = np.asarray(cand_d, dtype=np.float64)
+                if np.all(np.isnan(cand_d)):
+                    best = 0                                      # np.sort puts NaN last; dist_sorted[0] is NaN
+                else:
+                    best = int(np.nanargmin(cand_d))              # first of the smallest distance
+                if cand[best] == -1:
+                    raypack_refine.add(ray)
+                else:
+                    raypack_refine.add_fan(fan, [ray_id * n_rays + cand[best]])
+            self._angular_precision /= n_rays
+            self.dist_avg = np.mean(raypack_refine.dist_sorted)
+            if self.verbose:
+                print(f'{self._vi}Refine #{self.n_refines} mean distance: {self.dist_avg}')
+            self.pack_default = pack_refine
