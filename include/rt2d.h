@@ -98,7 +98,8 @@ typedef struct {
     int32_t backprop;        /* default 1 */
     int32_t has_target;      /* 0/1: when 1, dist_to_target / step_target / T_target are produced */
     double  target[2];
-    int32_t rebound_cap;     /* slots per ray in the rebound log arrays (>= n_rebounds_max+1 when bounded) */
+    int32_t rebound_cap;     /* slots per ray in the rebound log arrays; a ray with more rebounds gets
+                                RT2D_RAY_ERR_REBOUND_LOG (n_rebounds_max+1 slots always suffice when bounded) */
     int32_t reserved;
     double  power_cutoff;    /* <= 0: off (reference behaviour).  > 0: stop the ray at the first point whose
                                 transmittance 10^(G/10) at cutoff_freq falls below it (opt-in, SURVEY trap 2) */

@@ -211,6 +211,26 @@ class OracleEnv:
         self.cenv.floor = self._lin(floor)
         self.cenv.ceil = self._lin(ceil)
 
+    @classmethod
+    def from_tables(cls, tables, range_min, range_max):
+        """Oracle environment over GIVEN tables ({name: object with .breaks, .coef, .oob}; names as in
+        Rt2dEnvDesc, absorb0..absorb5).  Used to compare the HIP kernels with the C restatement bit for bit:
+        both then read the very same numbers."""
+        self = cls.__new__(cls)
+        self.range_min = np.asarray(range_min, dtype=float)
+        self.range_max = np.asarray(range_max, dtype=float)
+        self._keep = []
+        self.cenv = OrcEnv()
+        self.cenv.range_min[:] = list(self.range_min)
+        self.cenv.range_max[:] = list(self.range_max)
+        for name in ('c', 'dz_c', 'floor', 'ceil', 'dx_floor', 'dx_ceil', 'impedance'):
+            t = tables[name]
+            setattr(self.cenv, name, self._table(t.breaks, t.coef, t.oob))
+        for k in range(6):
+            t = tables[f'absorb{k}']
+            self.cenv.absorb[k] = self._table(t.breaks, t.coef, t.oob)
+        return self
+
     def _table(self, breaks, coef, oob):
         breaks = np.ascontiguousarray(breaks, dtype=np.float64)
         coef = np.ascontiguousarray(coef, dtype=np.float64)
@@ -295,6 +315,39 @@ def cast_ray(env, source, angle, params, init=None, cap=None, post=True):
         else:
             r.step_target = r.T_target = r.dist_to_target = None
     return r
+
+
+def ray_from_points(XZ, reb_step=(), reb_surface=(), reb_velocity=(), reb_angle=(), reb_pz=(), status=0):
+    """Oracle ray over GIVEN points and rebound log (e.g. the GPU's own), to check later stages in isolation."""
+    r = OracleRay()
+    r.XZ = np.ascontiguousarray(XZ, dtype=np.float64)
+    r.steps = int(r.XZ.shape[0])
+    r.reb_step = np.ascontiguousarray(reb_step, dtype=np.int32)
+    r.reb_surface = np.ascontiguousarray(reb_surface, dtype=np.uint8)
+    r.reb_velocity = np.ascontiguousarray(reb_velocity, dtype=np.float64)
+    r.reb_angle = np.ascontiguousarray(reb_angle, dtype=np.float64)
+    r.reb_pz = np.ascontiguousarray(reb_pz, dtype=np.float64)
+    r.n_rebounds = len(r.reb_step)
+    r.status = status
+    return r
+
+
+def post_ray(env, r, target=None):
+    """Post-pass of one oracle ray in place (ray.py:263-287); returns dist_to_target (NaN without target)."""
+    L = lib()
+    n = r.steps
+    r.dL_full, r.L, r.C, r.dT_full, r.T = (np.empty(n) for _ in range(5))
+    rng = np.empty(4)
+    st, tt, dd = C.c_int32(-1), C.c_double(np.nan), C.c_double(np.nan)
+    X, Z = np.ascontiguousarray(r.XZ[:, 0]), np.ascontiguousarray(r.XZ[:, 1])
+    tgt = None if target is None else np.ascontiguousarray(target, dtype=np.float64)
+    L.orc_post(C.byref(env.cenv), _dp(X), _dp(Z), n, _dp(tgt) if tgt is not None else None,
+               _dp(r.dL_full), _dp(r.L), _dp(r.C), _dp(r.dT_full), _dp(r.T), _dp(rng),
+               C.byref(st), C.byref(tt), C.byref(dd))
+    r.dL, r.dT = r.dL_full[1:], r.dT_full[1:]
+    r.range_min, r.range_max = rng[:2].copy(), rng[2:].copy()
+    r.step_target, r.T_target, r.dist_to_target = st.value, tt.value, dd.value
+    return dd.value
 
 
 def gain(env, ray, freq):

@@ -81,6 +81,9 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise Rt2dError(f'{SO_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                         '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
+    # torch ships its own copy of the HIP runtime; it has to be in the process BEFORE this library so that both
+    # resolve to the same runtime (and device pointers mean the same thing on both sides)
+    import torch  # noqa: F401
     L = C.CDLL(SO_PATH)
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     L.rt2d_last_error.restype = C.c_char_p

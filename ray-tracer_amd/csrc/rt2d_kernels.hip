@@ -766,13 +766,12 @@ static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const
                           const double* init_slope, const double* init_mult, const Rt2dRayOut* out) {
     if (!env || !src || !p || !out) return fail("rt2d_cast: null argument");
     if (n < 0) return fail("rt2d_cast: negative ray count");
+    if (n == 0) return 0;
     if (!angles && !(init_slope && init_mult)) return fail("rt2d_cast: angles is null");
     if ((init_slope == nullptr) != (init_mult == nullptr)) return fail("rt2d_cast: init_slope and init_mult go together");
     if (!(p->dx_max > 0) || !(p->dz_max > 0)) return fail("rt2d_cast: dx_max and dz_max must be positive");
     if (p->n_steps_max < 0) return fail("rt2d_cast: negative n_steps_max");
     if (p->rebound_cap < 0) return fail("rt2d_cast: negative rebound_cap");
-    if (p->n_rebounds_max > -1 && p->rebound_cap < p->n_rebounds_max + 1 && out->reb_step)
-        return fail("rt2d_cast: rebound_cap %d < n_rebounds_max + 1 = %d", p->rebound_cap, p->n_rebounds_max + 1);
     if (p->power_cutoff > 0) return fail("rt2d_cast: power_cutoff is not implemented in this build");
     return 0;
 }

@@ -30,9 +30,17 @@ SALINITY_DEFAULT = 35
 _t = np.array(_TEMPERATURE_SAMPLES, dtype=np.float64)[::-1]
 _p = np.array(_PH_SAMPLES, dtype=np.float64)[::-1]
 #: temperature [deg C] as a quadratic interpolant with extrapolation (reference: profile_temperature.py:30-36)
-calc_T = quadratic_interp_table(_t[:, 0], _t[:, 1], oob=OOB_EXTRAPOLATE)
 #: pH as a linear interpolant with extrapolation (reference: profile_ph.py:27-33)
-calc_pH = linear_interp_table(_p[:, 0], _p[:, 1], oob=OOB_EXTRAPOLATE)
+# These two only produce the O(500) samples the depth tables are built from.  dc/dz is a difference of
+# neighbouring c samples, so one ulp of T moves it by 1e-12 relative and the ray dynamics amplify that further;
+# with scipy present the samples are therefore taken from the same interp1d objects the reference uses.
+try:
+    from scipy.interpolate import interp1d as _interp1d
+    calc_T = _interp1d(_t[:, 0], _t[:, 1], kind='quadratic', bounds_error=False, fill_value='extrapolate')
+    calc_pH = _interp1d(_p[:, 0], _p[:, 1], kind='linear', bounds_error=False, fill_value='extrapolate')
+except ImportError:                         # pragma: no cover
+    calc_T = quadratic_interp_table(_t[:, 0], _t[:, 1], oob=OOB_EXTRAPOLATE)
+    calc_pH = linear_interp_table(_p[:, 0], _p[:, 1], oob=OOB_EXTRAPOLATE)
 
 
 def calc_S(z):

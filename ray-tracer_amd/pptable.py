@@ -14,10 +14,18 @@ expression, so host ``PPTable.__call__`` and device lookups agree bit for bit.
 
 ``quadratic_interp_table`` builds the same spline as ``interp1d(kind='quadratic')``
 (= ``make_interp_spline(k=2)``: knots at the mid-points of the data sites, not-a-knot ends)
-with a tridiagonal collocation solve written here, no scipy on the product path.
+.  The collocation solve is delegated to scipy when it is importable (the reference itself needs
+scipy), so the B-spline coefficients are the reference's to the last bit -- this matters because the ray
+dynamics amplify table differences by up to 1e6 ("Sensitivity") -- and falls back to the
+tridiagonal solve written here otherwise.  Only the power-basis conversion and the evaluation are ours.
 """
 
 import numpy as np
+
+try:                                        # host-side table construction only; never on the compute path
+    from scipy.interpolate import make_interp_spline as _make_interp_spline
+except ImportError:                         # pragma: no cover
+    _make_interp_spline = None
 
 OOB_EXTRAPOLATE = 0   # continue the end pieces (interp1d fill_value='extrapolate')
 OOB_CLAMP = 1         # clamp x into [breaks[0], breaks[-1]] (np.interp-style end values)
@@ -156,7 +164,13 @@ def quadratic_spline_pieces(x, y):
                 upper[i] = v
             elif v != 0.0:   # only at the two end rows, where the out-of-band weight is exactly 0
                 raise AssertionError('collocation matrix is not tridiagonal')
-    c = _solve_tridiagonal(lower, diag, upper, y)
+    c = None
+    if _make_interp_spline is not None:
+        spl = _make_interp_spline(x, y, k=2, check_finite=False)
+        if spl.t.shape == t.shape and np.array_equal(spl.t, t):
+            c = np.asarray(spl.c, dtype=np.float64)
+    if c is None:
+        c = _solve_tridiagonal(lower, diag, upper, y)
 
     # Power basis about the left break of each span m = 2 .. n-1 (piece j = m - 2).
     m = np.arange(2, n)

@@ -172,6 +172,27 @@ class RayFan:
         base = int(self.host('tile_off')[i // TILE]) + (i % TILE)
         return tensor[base::TILE][:int(self.host('n_pts')[i])]
 
+    def padded_host(self, tensor_x=None, tensor_z=None):
+        """(X, Z, valid) as (n, max_pts) NumPy arrays, NaN-padded: the whole fan's points on the host."""
+        self._need_store()
+        X = self.X if tensor_x is None else tensor_x
+        Z = self.Z if tensor_z is None else tensor_z
+        n_pts, off = self.host('n_pts'), self.host('tile_off')
+        m = int(n_pts.max()) if self.n else 0
+        outx = np.full((self.n, m), np.nan)
+        outz = np.full((self.n, m), np.nan)
+        for t in range(len(off) - 1):
+            steps = int(off[t + 1] - off[t]) // TILE
+            lanes = min(TILE, self.n - t * TILE)
+            bx = X[int(off[t]):int(off[t + 1])].view(steps, TILE).cpu().numpy()
+            bz = Z[int(off[t]):int(off[t + 1])].view(steps, TILE).cpu().numpy()
+            outx[t * TILE:t * TILE + lanes, :steps] = bx.T[:lanes]
+            outz[t * TILE:t * TILE + lanes, :steps] = bz.T[:lanes]
+        valid = np.arange(m)[None, :] < n_pts[:, None]
+        outx[~valid] = np.nan
+        outz[~valid] = np.nan
+        return outx, outz, valid
+
     # -- post-pass arrays (ray.py:271-275) --------------------------------------------------------
     def post(self):
         if self._post is None:

@@ -1,0 +1,186 @@
+"""GPU parity of the gain kernel (rt2d_gain), the post-pass (rt2d_post), rt2d_dist and the heat-map kernels."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+from common import SCALAR_RTOL, KNIFE_EDGE_M
+
+pytestmark = pytest.mark.gpu
+
+GAIN_RTOL = 1e-9      # cumulative gain [dB] relative tolerance vs the reference
+HEAT_RTOL = 1e-9      # heat-map cell tolerance (relative to the cell value)
+
+
+def _cast(rt, g, angles=None, **over):
+    env = common.product_env(rt, g)
+    kw = common.prop_kwargs(g)
+    kw.update(over)
+    fan = rt.RayFan(env, g['fan_source'], g['fan_angles'] if angles is None else angles, target=common.target_of(g), **kw)
+    return fan, env
+
+
+def _oracle_rays_from_fan(orc, rt, fan):
+    return common.oracle_rays_from_fan(orc, rt, fan)
+
+
+def _oracle_post(orc, oenv, r, target=None):
+    return orc.post_ray(oenv, r, target)
+
+
+def test_post_arrays_bit_exact(rt, orc):
+    """dL, L, C, dT, T of rt2d_post equal the oracle's bit for bit on the same points (ray.py:271-275)."""
+    g = common.load('c3_bathy250')
+    fan, env = _cast(rt, g)
+    oenv = common.oracle_env_from_product(orc, env)
+    rays = _oracle_rays_from_fan(orc, rt, fan)
+    for i in range(0, fan.n, 7):
+        _oracle_post(orc, oenv, rays[i])
+        ray = rt.Ray2D._from_fan(fan, i)
+        assert np.array_equal(ray.dL, rays[i].dL_full[1:])
+        assert np.array_equal(ray.L, rays[i].L)
+        assert np.array_equal(ray.C, rays[i].C)
+        assert np.array_equal(ray.dT, rays[i].dT_full[1:])
+        assert np.array_equal(ray.T, rays[i].T)
+        assert ray.T[-1] == fan.host('T_end')[i] and ray.L[-1] == fan.host('L_end')[i]
+
+
+def test_dist_kernel(rt, orc):
+    """rt2d_dist on stored trajectories == the in-kernel distance == the oracle's sorted interpolation."""
+    g = common.load('c1_flat250')
+    fan, env = _cast(rt, g)
+    oenv = common.oracle_env_from_product(orc, env)
+    d2 = fan.dist_to(g['fan_target']).cpu().numpy()
+    np.testing.assert_array_equal(d2, fan.host('dist'))
+    rays = _oracle_rays_from_fan(orc, rt, fan)
+    for i in range(0, fan.n, 5):
+        d = _oracle_post(orc, oenv, rays[i], target=g['fan_target'])
+        assert (np.isnan(d) and np.isnan(d2[i])) or d == d2[i]
+    # a target left of every point and one exactly at the source abscissa
+    assert np.all(np.isnan(fan.dist_to([-5., -100.]).cpu().numpy()))
+    d0 = fan.dist_to([0., -100.]).cpu().numpy()
+    for i in range(0, fan.n, 25):
+        assert d0[i] == _oracle_post(orc, oenv, rays[i], target=np.array([0., -100.]))
+
+
+@pytest.mark.parametrize('name', ['c4_multifreq', 'c2_fan999', 't2_single'])
+def test_gain_vs_reference(rt, name):
+    """populate_NEW against the reference's G (end values and sampled points)."""
+    g = common.load(name)
+    fan, env = _cast(rt, g)
+    freqs = [float(f) for f in g['fan_freqs']]
+    fan.populate(*freqs)
+    ok = (g['error'] == 0) & (fan.host('n_pts') == g['steps'])
+    worst = 0.0
+    for k, f in enumerate(freqs):
+        ge = fan.G_end[f].cpu().numpy()
+        ref = g['G_end'][k]
+        fin = ok & np.isfinite(ref)
+        assert np.array_equal(np.isneginf(ge[ok]), np.isneginf(ref[ok]))
+        e = np.abs(ge[fin] - ref[fin]) / np.maximum(1e-3, np.abs(ref[fin]))
+        worst = max(worst, e.max(initial=0))
+        for i in np.nonzero(fin)[0][::17]:
+            gi = fan.ray_slice(fan.G[f], int(i)).cpu().numpy()[g['sample_idx'][i]]
+            ri = g['sample_G'][k, i]
+            m = np.isfinite(ri)
+            assert np.all(np.abs(gi[m] - ri[m]) <= GAIN_RTOL * np.maximum(1e-3, np.abs(ri[m])) * 100)
+    print(f'{name}: worst relative gain error at ray end {worst:.2e} over {len(freqs)} frequencies')
+    assert worst < 1e-7
+    # per-ray view
+    ray = rt.Ray2D._from_fan(fan, 0)
+    ray.populate_NEW(*freqs[:2])
+    assert ray.freqs == sorted(freqs[:2]) and ray.G[freqs[0]].shape[0] == ray.steps
+
+
+def test_gain_vs_oracle_same_points(rt, orc):
+    """Gain kernel in isolation: the oracle integrates over the GPU's own points and rebound log."""
+    g = common.load('c2_fan999')
+    fan, env = _cast(rt, g, angles=g['fan_angles'][::9])
+    oenv = common.oracle_env_from_product(orc, env)
+    freqs = [1, 250., 1000., 4000., 10000., 12345.6, 20000., 3., 7., 11.]      # 10 -> two frequency chunks
+    fan.populate(*freqs)
+    rays = _oracle_rays_from_fan(orc, rt, fan)
+    worst = 0.0
+    for i, r in enumerate(rays):
+        if r.status != 0:
+            continue
+        _oracle_post(orc, oenv, r)
+        for f in freqs:
+            G = orc.gain(oenv, r, f)
+            Gd = fan.ray_slice(fan.G[f], i).cpu().numpy()
+            assert np.array_equal(np.isfinite(G), np.isfinite(Gd))
+            m = np.isfinite(G)
+            worst = max(worst, (np.abs(G[m] - Gd[m]) / np.maximum(1e-6, np.abs(G[m]))).max(initial=0))
+            assert Gd[-1] == fan.G_end[f][i].item() or (np.isneginf(Gd[-1]) and np.isneginf(fan.G_end[f][i].item()))
+    print(f'gain kernel vs oracle on identical points: worst relative error {worst:.2e}')
+    assert worst < 1e-11
+
+
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name):
+    """Binning in isolation: oracle heat map over the GPU's own points and gains -> every cell equal to 1e-12."""
+    g = common.load(name)
+    fan, env = _cast(rt, g)
+    oenv = common.oracle_env_from_product(orc, env)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    sim.raypacks['main'].add_fan(fan)
+    H, dropped = sim.heatmap_full(resolution=[50, 25])
+    H = H.cpu().numpy()
+    rays = [r for r in _oracle_rays_from_fan(orc, rt, fan) if r.status == 0]
+    for r in rays:
+        _oracle_post(orc, oenv, r)
+    Href, plot_ref, drop_ref = orc.heatmap(oenv, rays, res=(50, 25), cutoff=.02)
+    assert H.shape == Href.shape
+    assert int(dropped.item()) == drop_ref
+    assert np.array_equal(H == 0, Href == 0), f'{int(((H == 0) != (Href == 0)).sum())} cells differ in occupancy'
+    rel = np.abs(H - Href) / np.maximum(1e-300, np.abs(Href))
+    assert rel[Href != 0].max() < 1e-12
+    for cutoff in (.02, .1, .5):
+        out = sim.heatmap(resolution=[50, 25], cutoff=cutoff, reduction_power=.5)
+        _, plot_ref, _ = orc.heatmap(oenv, rays, res=(50, 25), cutoff=cutoff)
+        assert out.shape == plot_ref.shape
+        assert np.abs(out - plot_ref).max() < 1e-12
+
+
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+def test_heatmap_vs_reference(rt, name):
+    """Whole pipeline against the reference's heat map; bin-edge disagreements are counted and bounded."""
+    g = common.load(name)
+    fan, env = _cast(rt, g)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    sim.raypacks['main'].add_fan(fan)
+    pack = sim.raypacks['main']
+    assert pack.n_rays == int((g['error'] == 0).sum())
+    assert np.allclose(pack.range_min_plot, g['range_min_plot'], rtol=1e-9) and np.allclose(pack.range_max_plot, g['range_max_plot'], rtol=1e-9)
+    H, dropped = sim.heatmap_full(resolution=[int(v) for v in g['heatmap_res']])
+    H = H.cpu().numpy()
+    ref = g['heatmap_full']
+    assert H.shape == ref.shape and int(dropped.item()) == 0
+    knife = fan.host('margin') <= KNIFE_EDGE_M
+    differ = np.abs(H - ref) > HEAT_RTOL * np.maximum(1.0, np.abs(ref))
+    n_bad = int(differ.sum())
+    # Cells that may legitimately differ: (a) cells next to a point that sits on a cell edge to within 1e-6 m
+    # (dz_max equals the cell height, so steep rays land on multiples of 25 m and the last bits decide the bin),
+    # (b) any cell visited by a knife-edge ray (its later points may be shifted by one step).
+    res = [int(v) for v in g['heatmap_res']]
+    X, Z, valid = fan.padded_host()
+    suspect = np.zeros(H.shape, dtype=bool)
+    fx, fz = X / res[0], Z / res[1]
+    edge = valid & ((np.abs(fx - np.round(fx)) < 1e-6 / res[0]) | (np.abs(fz - np.round(fz)) < 1e-6 / res[1]))
+    edge |= valid & knife[:, None]
+    ix = np.floor_divide(np.trunc(X[edge]).astype(np.int64), res[0])
+    iz = np.floor_divide(np.trunc(Z[edge]).astype(np.int64), -res[1])
+    for dx in (-1, 0, 1):
+        for dz in (-1, 0, 1):
+            a, b = ix + dx, iz + dz
+            m = (a >= 0) & (a < H.shape[0]) & (b >= 0) & (b < H.shape[1])
+            suspect[a[m], b[m]] = True
+    print(f'{name}: heat map {H.shape}: {n_bad} of {H.size} cells differ from the reference; '
+          f'{int((differ & ~suspect).sum())} of them are NOT explained by a cell-edge / knife-edge point '
+          f'(edge points: {int(edge.sum())}, knife-edge rays: {int(knife.sum())})')
+    assert int((differ & ~suspect).sum()) == 0
+    assert n_bad <= 0.02 * H.size
+    # the mass of the map moves by at most ~one deposit per edge point (a flip can merge two cells of one ray)
+    assert abs(H.sum() - ref.sum()) <= 1e-9 * ref.sum() + 2.0 * int(edge.sum())
