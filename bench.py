@@ -1,0 +1,276 @@
+"""bench.py -- the reference's headline workload on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one fan: cast (count pass, tile layout, store pass) ->
+gain at 1 Hz -> heat-map accumulation -> normalise/clip/power, everything on the device, inputs (the angle
+array and the environment tables) resident in HBM before the timed region.  At N = 1 the fan is BASELINE
+config 1: 999 rays (angles -i/1000), 20 rebounds, dx_max 50 / dz_max 25, floor max(-e^{0.0005x}-500,
+-1500+0.02x) over 75 km.  At N > 1 every rank casts 999 rays of the N-times denser fan -(j+1)/(1000 N)
+(ray j on rank j mod N, weak scaling); the plot range and the heat map are combined with the two RCCL
+all-reduces of ray-tracer_amd/parallel.py.
+
+Prints ONE JSON line on rank 0: metric ray-steps/s (whole job), per-stage kernel times from HIP events,
+`roofline` of the dominant kernel (the storing cast: 16 B per ray-step against HBM), a `large_fan` block
+(the same pipeline on --large-rays rays, where the GPU is actually full) and `cpu_baseline`
+(oracle/rt2d_oracle.c, scalar, 1 core, same fan).
+"""
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6 # vendor figure
+BYTES_PER_STEP = 16            # x, z as f64 per appended point, storing cast
+FLOP_PER_STEP = 48
+
+
+def c2_floor(x):
+    return np.maximum(-1 * np.exp(0.0005 * x) - 500, -1500 + 0.02 * x)
+
+
+def make_env(rt):
+    xs = np.linspace(0., 75000., 3001)
+    return rt.Environment2D((xs, c2_floor(xs)), (np.array([0., 75000.]), np.array([0., 0.])),
+                            np.array([0., -1501.]), np.array([75000., 1.]))
+
+
+PROP = dict(dx_max=50., dz_max=25., n_rebounds_max=20)
+RES = (50, 25)
+
+
+class Stages:
+    """HIP-event timing of the device stages of one step (events on torch's current stream, which is the
+    stream every rt2d_* launch uses)."""
+    NAMES = ('cast_count', 'layout', 'cast_store', 'gain', 'heatmap', 'finalize')
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.records = []
+
+    def new_step(self):
+        ev = [self.torch.cuda.Event(enable_timing=True) for _ in range(len(self.NAMES) + 1)]
+        self.records.append(ev)
+        return ev
+
+    def summary(self):
+        out = {}
+        for k, name in enumerate(self.NAMES):
+            out[name] = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for ev in self.records]))
+        return out
+
+
+def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False, device=None):
+    """The hot path once.  Returns (ray_steps, heat map (nz, nx) device tensor)."""
+    from ray_tracer_amd import _lib, parallel
+    L = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = stages.new_step() if stages is not None else None
+    n = int(angles_dev.shape[0])
+    f64 = dict(dtype=torch.float64, device=device)
+    i32 = dict(dtype=torch.int32, device=device)
+    handle = env.device_handle(device.index)
+    n_pts, stop, nreb, status = (torch.empty(n, **i32) for _ in range(4))
+    rng = torch.empty((4, n), **f64)
+    out = _lib.Rt2dRayOut()
+    out.n_pts, out.stop_code, out.n_rebounds, out.status = n_pts.data_ptr(), stop.data_ptr(), nreb.data_ptr(), status.data_ptr()
+    out.range = rng.data_ptr()
+    src = (C.c_double * 2)(float(source[0]), float(source[1]))
+    p = _lib.Rt2dParams()
+    p.dx_max, p.dz_max, p.n_steps_max, p.n_rebounds_max, p.backprop = PROP['dx_max'], PROP['dz_max'], 100000, PROP['n_rebounds_max'], 1
+    cap = PROP['n_rebounds_max'] + 1
+    p.rebound_cap = cap
+    if ev: ev[0].record()
+    _lib.check(L.rt2d_cast_count(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(out), stream))
+    if ev: ev[1].record()
+    n_tiles = (n + 63) // 64
+    tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=device)
+    total = C.c_int64(0)
+    _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), C.byref(total), stream))
+    total = int(total.value)
+    if ev: ev[2].record()
+    X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
+    reb_step = torch.empty((cap, n), **i32)
+    reb_surface = torch.empty((cap, n), dtype=torch.uint8, device=device)
+    reb_vel, reb_ang, reb_px, reb_pz = (torch.empty((cap, n), **f64) for _ in range(4))
+    out.reb_step, out.reb_surface, out.reb_velocity = reb_step.data_ptr(), reb_surface.data_ptr(), reb_vel.data_ptr()
+    out.reb_angle, out.reb_pos_x, out.reb_pos_z = reb_ang.data_ptr(), reb_px.data_ptr(), reb_pz.data_ptr()
+    _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(out),
+                                 tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(), None, stream))
+    if ev: ev[3].record()
+    G = torch.empty(total, **f64)
+    freq = torch.ones(1, **f64)
+    _lib.check(L.rt2d_gain(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap, n,
+                           freq.data_ptr(), 1, total, G.data_ptr(), None, stream))
+    if ev: ev[4].record()
+    # plot range of the rays that did not fail (RayPack2D.add fold, origin included) -> heat-map shape
+    okm = (status == 0)
+    big = torch.finfo(torch.float64).max
+    lo = torch.minimum(torch.where(okm, rng[:2], torch.full_like(rng[:2], big)).amin(dim=1), torch.zeros(2, **f64))
+    hi = torch.maximum(torch.where(okm, rng[2:], torch.full_like(rng[2:], -big)).amax(dim=1), torch.zeros(2, **f64))
+    lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+    if collectives:
+        lo, hi = parallel.allreduce_plot_range(lo, hi, device=device)          # C1
+    shape = parallel.heatmap_shape(lo, hi, RES)
+    H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)
+    ids = torch.nonzero(okm).flatten().to(torch.int32)
+    res_c = (C.c_int32 * 2)(*RES)
+    shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+    _lib.check(L.rt2d_heatmap_accumulate(X.data_ptr(), Z.data_ptr(), G.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), n,
+                                         ids.data_ptr(), int(ids.shape[0]), res_c, shape_c, H.data_ptr(), None, stream))
+    if collectives:
+        parallel.allreduce_heatmap(H)                                          # C2
+    if ev: ev[5].record()
+    outp = torch.empty(int(shape[0]) * int(shape[1]), **f64)
+    scratch = torch.empty(2, **f64)
+    _lib.check(L.rt2d_heatmap_finalize(H.data_ptr(), shape_c, .02, .5, outp.data_ptr(), scratch.data_ptr(), stream))
+    if ev: ev[6].record()
+    return total, n_pts, status, outp.view(int(shape[1]), int(shape[0]))
+
+
+def ray_steps_of(n_pts, status):
+    ok = status == 0
+    return int((n_pts[ok] - 1).sum().item())
+
+
+def cpu_baseline(seconds=4.0):
+    """oracle/rt2d_oracle.c (scalar port of the reference's algorithm) on this host, 1 core, same C2 fan."""
+    from oracle import oracle as orc
+    xs = np.linspace(0., 75000., 3001)
+    oenv = orc.OracleEnv(orc.LinearFloor(xs, c2_floor(xs)), orc.LinearFloor([0., 75000.], [0., 0.]),
+                         [0., -1501.], [75000., 1.])
+    angles = np.array([i / 1000 for i in range(-1, -1000, -1)])
+    p = orc.make_params(**PROP)
+    orc.run_fan(oenv, [0., 0.], angles[:50], p)       # warm
+    reps, steps, t0 = 0, 0, time.perf_counter()
+    while True:
+        s, H, nerr = orc.run_fan(oenv, [0., 0.], angles, p, freq=1, res=RES)
+        steps += s; reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    # run_fan makes two propagation passes (range, then binning), like the GPU's count + store passes
+    return {'value': steps / dt, 'unit': 'ray-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{reps} x the full 999-ray C2 fan (cast x2 + post + gain@1Hz + heat map) in {dt:.2f} s, '
+                      f'{s} ray-steps per fan', 's_per_heatmap': dt / reps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--large-rays', type=int, default=1 << 20, help='rays of the large-fan block (0 = skip)')
+    ap.add_argument('--large-steps', type=int, default=3)
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    import rt2d_loader
+    rt = rt2d_loader.load()
+    env = make_env(rt)
+    source = np.array([0., 0.])
+    n_fan = 999
+    j = np.arange(rank, n_fan * world, world)                       # ray j of the N-times denser fan on rank j % N
+    angles = -(j + 1) / (1000.0 * world)
+    angles_dev = torch.from_numpy(angles).to(device)
+    env.device_handle(device.index)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(rt, torch, env, source, angles_dev, collectives=world > 1, device=device)
+    stages = Stages(torch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, n_pts, status, hm = one_step(rt, torch, env, source, angles_dev, stages=stages, collectives=world > 1, device=device)
+    barrier()
+    dt = time.perf_counter() - t0
+    steps_rank = ray_steps_of(n_pts, status)
+    t = torch.tensor([dt, float(steps_rank)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, steps_all = float(tmax[0].item()), float(tsum[1].item())
+    else:
+        steps_all = float(steps_rank)
+    st = stages.summary()
+
+    result = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = steps_all * args.steps / dt
+        store_ms = st['cast_store']
+        achieved = steps_rank * BYTES_PER_STEP / (store_ms * 1e-3) / 1e9
+        result = {
+            'metric': 'ray-steps/sec (node) + s per 999-ray 20-rebound heatmap', 'value': value, 'unit': 'ray-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'c2_fan999: 999 rays/GPU (-(j+1)/(1000 N) rad), 20 rebounds, dx_max 50, dz_max 25, '
+                                   'floor max(-e^{0.0005x}-500,-1500+0.02x) over 75 km, gain @1 Hz, heat map 50x25 m',
+                       'rays_per_gpu': n_fan, 'ray_steps_per_gpu': steps_rank, 'heatmap_shape': list(hm.shape)},
+            's_per_heatmap': dt / args.steps,
+            'stage_ms': st,
+            'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'note': '999 rays = 16 wavefronts on 256 CUs: latency-bound by construction; see large_fan',
+                         'fp64_valu_frac': steps_rank * FLOP_PER_STEP / (store_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+        }
+
+    # the same pipeline where the GPU is full (single-GPU block, rank 0 only prints it)
+    if args.large_rays > 0 and world == 1:
+        nL = args.large_rays
+        big_angles = torch.from_numpy(-(np.arange(nL) + 1) * (0.999 / nL)).to(device)
+        one_step(rt, torch, env, source, big_angles, device=device)
+        stages_l = Stages(torch)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.large_steps):
+            _, n_pts_l, status_l, _ = one_step(rt, torch, env, source, big_angles, stages=stages_l, device=device)
+        torch.cuda.synchronize(); dtl = time.perf_counter() - t0
+        sl = ray_steps_of(n_pts_l, status_l)
+        stl = stages_l.summary()
+        ach = sl * BYTES_PER_STEP / (stl['cast_store'] * 1e-3) / 1e9
+        result['large_fan'] = {
+            'rays': nL, 'ray_steps': sl, 'value': sl * args.large_steps / dtl, 'unit': 'ray-steps/s',
+            's_per_heatmap': dtl / args.large_steps, 'stage_ms': stl,
+            'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'fp64_valu_frac': sl * FLOP_PER_STEP / (stl['cast_store'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         'count_pass_steps_per_s': sl / (stl['cast_count'] * 1e-3)},
+        }
+        del big_angles
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            result['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -82,6 +82,9 @@ def lib():
         _lib.orc_heatmap_finalize.argtypes = [dp, ip, C.c_double, C.c_double, dp]
         _lib.orc_table_eval.restype = C.c_double
         _lib.orc_table_eval.argtypes = [C.POINTER(OrcTable), C.c_double, ip]
+        _lib.orc_run_fan.restype = C.c_int64
+        _lib.orc_run_fan.argtypes = [C.POINTER(OrcEnv), dp, dp, C.c_int64, C.POINTER(OrcParams), C.c_double,
+                                     C.c_double, C.c_double, ip, ip, dp, dp, C.POINTER(C.c_int64)]
         _lib.orc_absorption.restype = C.c_double
         _lib.orc_absorption.argtypes = [C.POINTER(OrcEnv), C.c_double, C.c_double]
     return _lib
@@ -386,3 +389,21 @@ def heatmap(env, rays, res=(50, 25), reduction_power=.5, cutoff=.02, freq=1):
     out = np.empty(int(shape[0]) * int(shape[1]))
     L.orc_heatmap_finalize(_dp(H), _ip(shape), float(cutoff), float(reduction_power), _dp(out))
     return H.reshape(shape[0], shape[1]), out.reshape(shape[1], shape[0]), dropped
+
+
+def run_fan(env, source, angles, params, freq=1, res=(50, 25)):
+    """Whole hot path for a fan in C (cast + post + gain + heat map), as timed by bench.py's cpu_baseline.
+    Returns (ray_steps, heatmap_full (nx, nz), n_errors)."""
+    L = lib()
+    src = np.asarray(source, dtype=np.float64)
+    ang = np.ascontiguousarray(angles, dtype=np.float64)
+    res = np.asarray(res, dtype=np.int32)
+    rng = np.zeros(4)
+    nerr = C.c_int64(0)
+    L.orc_run_fan(C.byref(env.cenv), _dp(src), _dp(ang), len(ang), C.byref(params), float(freq), ZP1, ZP2,
+                  _ip(res), None, None, _dp(rng), C.byref(nerr))
+    shape = (np.ceil((rng[2:] - rng[:2]) / res).astype(int) + 1).astype(np.int32)
+    H = np.zeros(int(shape[0]) * int(shape[1]))
+    steps = L.orc_run_fan(C.byref(env.cenv), _dp(src), _dp(ang), len(ang), C.byref(params), float(freq), ZP1, ZP2,
+                          _ip(res), _ip(shape), _dp(H), _dp(rng), C.byref(nerr))
+    return int(steps), H.reshape(int(shape[0]), int(shape[1])), int(nerr.value)

@@ -345,3 +345,44 @@ void orc_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, 
         out[iz * nx + ix] = v;
     }
 }
+
+/* ---- whole-fan driver for the CPU baseline (bench.py cpu_baseline): cast + post + gain(freq) + heat map,
+ * one ray after the other as Simulation2D.cast / heatmap do (simulation.py:89-94, 120-131).  The heat map
+ * shape comes from the caller (a first call with H = NULL returns the plot range in range4).
+ * Returns the number of ray-steps (appended points). */
+int64_t orc_run_fan(const OrcEnv* env, const double* src, const double* angles, int64_t n, const OrcParams* p,
+                    double freq, double Zp1, double Zp2, const int32_t* res, const int32_t* shape, double* H,
+                    double* range4, int64_t* n_errors) {
+    const int64_t cap = (int64_t)p->n_steps_max + 2;
+    double* X = (double*)malloc(sizeof(double) * cap), *Z = (double*)malloc(sizeof(double) * cap);
+    double* dL = (double*)malloc(sizeof(double) * cap), *L = (double*)malloc(sizeof(double) * cap);
+    double* C = (double*)malloc(sizeof(double) * cap), *dT = (double*)malloc(sizeof(double) * cap);
+    double* T = (double*)malloc(sizeof(double) * cap), *G = (double*)malloc(sizeof(double) * cap);
+    const int rc = p->rebound_cap > 0 ? p->rebound_cap : 1;
+    int32_t* rs = (int32_t*)malloc(sizeof(int32_t) * rc); uint8_t* rsurf = (uint8_t*)malloc(rc);
+    double* rv = (double*)malloc(sizeof(double) * rc), *ra = (double*)malloc(sizeof(double) * rc);
+    double* rpx = (double*)malloc(sizeof(double) * rc), *rpz = (double*)malloc(sizeof(double) * rc);
+    int64_t steps = 0, errors = 0;
+    double mn[2] = {0, 0}, mx[2] = {0, 0};                                /* ray.py:441-442 */
+    for (int64_t r = 0; r < n; ++r) {
+        int32_t n_pts, stop, n_reb; double margin, rng[4];
+        int32_t st = orc_propagate(env, src, angles[r], p, 0, 0, 0, X, Z, cap, &n_pts, &stop, &n_reb,
+                                   rs, rsurf, rv, ra, rpx, rpz, &margin);
+        if (st == -1) { ++errors; continue; }
+        int32_t stt; double Tt, dd;
+        orc_post(env, X, Z, n_pts, p->has_target ? p->target : NULL, dL, L, C, dT, T, rng, &stt, &Tt, &dd);
+        steps += n_pts - 1;
+        if (rng[0] < mn[0]) mn[0] = rng[0]; if (rng[1] < mn[1]) mn[1] = rng[1];
+        if (rng[2] > mx[0]) mx[0] = rng[2]; if (rng[3] > mx[1]) mx[1] = rng[3];
+        if (H) {
+            int nl = n_reb < rc ? n_reb : rc;
+            orc_gain(env, Z, dL, n_pts, freq, nl, rs, rsurf, rv, ra, rpz, Zp1, Zp2, G);
+            orc_heatmap_add(X, Z, G, n_pts, res, shape, H);
+        }
+    }
+    if (range4) { range4[0] = mn[0]; range4[1] = mn[1]; range4[2] = mx[0]; range4[3] = mx[1]; }
+    if (n_errors) *n_errors = errors;
+    free(X); free(Z); free(dL); free(L); free(C); free(dT); free(T); free(G);
+    free(rs); free(rsurf); free(rv); free(ra); free(rpx); free(rpz);
+    return steps;
+}

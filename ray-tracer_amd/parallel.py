@@ -1,0 +1,98 @@
+"""Multi-GPU partitioning of a ray fan: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm).
+
+Rays are independent (the reference loops ``for angle in angles``, simulation.py:89-94), so a fan shards
+with no data-path exchange until the heat map is assembled.  Exactly two collectives exist on this path:
+
+  C1  all-reduce(min/max) of the 4 plot-range doubles  (RayPack2D.add range fold, ray.py:466-472) -- fixes
+      the global heat-map shape before anything is binned;
+  C2  all-reduce(sum) of the nx*nz float64 heat map      (``heatmap_full +=`` across rays, simulation.py:131).
+
+Both are latency-bound over xGMI (4 doubles; ~0.6 MB at 50 m x 25 m cells), one RCCL call each.
+The functions work on any backend (the CPU tests run them under gloo with world_size 2).
+"""
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world():
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_angles(angles, rank=None, world_size=None, mode='interleave'):
+    """This rank's share of a fan.
+
+    'interleave' (default): ray j goes to rank j % world -- every rank sees the whole angular range, so
+    steep (short) and shallow (long) rays are spread evenly.  'block': contiguous blocks, which keeps
+    neighbouring lanes of a wavefront closest in length.  Returns (angles, global indices)."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    angles = np.asarray(angles, dtype=np.float64)
+    idx = np.arange(angles.shape[0])
+    if mode == 'interleave':
+        sel = idx[rank::world_size]
+    elif mode == 'block':
+        per = (angles.shape[0] + world_size - 1) // world_size
+        sel = idx[rank * per:(rank + 1) * per]
+    else:
+        raise ValueError(mode)
+    return angles[sel], sel
+
+
+def allreduce_plot_range(range_min_plot, range_max_plot, device=None):
+    """C1: global plot range.  Inputs are the local RayPack2D.range_min_plot / range_max_plot (2 doubles each)."""
+    import torch
+    dist = _dist()
+    lo = np.asarray(range_min_plot, dtype=np.float64)
+    hi = np.asarray(range_max_plot, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return lo.copy(), hi.copy()
+    # one collective: max over (-min, max)
+    t = torch.tensor(np.concatenate((-lo, hi)), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu().numpy()
+    return -t[:2], t[2:]
+
+
+def heatmap_shape(range_min_plot, range_max_plot, res):
+    """ceil(size_plot / res) + 1 (simulation.py:117)."""
+    size_plot = np.asarray(range_max_plot) - np.asarray(range_min_plot)
+    return (np.ceil(size_plot / np.asarray(res)).astype(int) + 1).astype(np.int64)
+
+
+def allreduce_heatmap(H):
+    """C2: sum the per-rank heat maps in place (a torch tensor on this rank's device)."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(H, op=dist.ReduceOp.SUM)
+    return H
+
+
+def allgather_topk(dist_local, angles_local, k):
+    """C3 (sweep + refine): the k globally smallest distances and their angles.  Each rank contributes its own
+    k best (NaN = never reaches the target abscissa) and the merge is done redundantly on every rank."""
+    import torch
+    dist = _dist()
+    d = torch.as_tensor(dist_local, dtype=torch.float64)
+    a = torch.as_tensor(angles_local, dtype=torch.float64, device=d.device)
+    d = torch.where(torch.isnan(d), torch.full_like(d, float('inf')), d)
+    kk = min(k, d.numel())
+    best = torch.topk(d, kk, largest=False)
+    cand = torch.full((2, k), float('inf'), dtype=torch.float64, device=d.device)
+    cand[0, :kk] = best.values
+    cand[1, :kk] = a[best.indices]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.empty_like(cand) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, cand)
+        cand = torch.cat(parts, dim=1)
+    order = torch.argsort(cand[0], stable=True)[:k]
+    out_d, out_a = cand[0, order], cand[1, order]
+    keep = torch.isfinite(out_d)
+    return out_d[keep], out_a[keep]
