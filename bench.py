@@ -123,11 +123,12 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         lo, hi = parallel.allreduce_plot_range(lo, hi, device=device)          # C1
     shape = parallel.heatmap_shape(lo, hi, RES)
     H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)
-    ids = torch.nonzero(okm).flatten().to(torch.int32)
+    mask = okm.to(torch.uint8)
+    work = torch.empty(n + 2, **i32)
     res_c = (C.c_int32 * 2)(*RES)
     shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
     _lib.check(L.rt2d_heatmap_accumulate(X.data_ptr(), Z.data_ptr(), G.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), n,
-                                         ids.data_ptr(), int(ids.shape[0]), res_c, shape_c, H.data_ptr(), None, stream))
+                                         mask.data_ptr(), res_c, shape_c, H.data_ptr(), None, work.data_ptr(), stream))
     if collectives:
         parallel.allreduce_heatmap(H)                                          # C2
     if ev: ev[5].record()

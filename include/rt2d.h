@@ -181,15 +181,18 @@ int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, con
  * value 10^(G/10)^-0.1 of the LAST point falling in each cell (x//res_x, z//-res_z) is added to H.
  * The cell arithmetic is the reference's integer arithmetic: trunc toward zero, then floor division, then the
  * flat index ix*nz + iz (negative flat indices wrap once, as NumPy indexing does).
- * ray_ids: device, n_sel ray indices to bin (NULL = all n rays; a RayPack may hold a subset of a fan).
+ * ray_mask: device, n bytes, nonzero = bin this ray (NULL = all n rays; a RayPack may hold a subset of a fan).
  * G: device, one frequency, tile layout.  res: host, 2 ints (metres per cell in x and z).
  * shape: host, 2 ints (nx, nz).  H: device, nx*nz doubles row-major [ix*nz + iz], accumulated into
  * (caller zeroes it).  n_dropped (device int64, may be NULL, caller zeroes it) counts points whose flat index
- * falls outside [-nx*nz, nx*nz) -- the reference raises IndexError there. */
+ * falls outside [-nx*nz, nx*nz) -- the reference raises IndexError there.
+ * work: device workspace of n + 2 int32 (contents irrelevant on entry), or NULL.  With a workspace and nz <= 256,
+ * rays that only move forward in x and stay inside the map are binned by a coalesced one-wave-per-tile kernel and
+ * only the remaining rays go through the general one-wave-per-ray hash kernel; without it every ray does. */
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
-                                const int32_t* n_pts, int64_t n, const int32_t* ray_ids, int64_t n_sel,
+                                const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                 const int32_t* res, const int32_t* shape,
-                                double* H, int64_t* n_dropped, void* stream);
+                                double* H, int64_t* n_dropped, int32_t* work, void* stream);
 
 /* Heat-map presentation (reference: simulation.py:133-138): out[iz*nx + ix] = min(H/max(H), cutoff)^power.
  * scratch: device, at least 2 doubles. */

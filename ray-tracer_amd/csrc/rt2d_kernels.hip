@@ -4,7 +4,7 @@
 //                         scalar post-pass (ray.py:263-287) folded in; environment tables staged in LDS;
 //                         trajectories stored step-major per 64-ray tile (one 512-B line per wave per step).
 //   rt2d_post_kernel      per-point dL, L, C, dT, T (ray.py:271-275).
-//   rt2d_gain_kernel      Ray2D.populate_NEW for F frequencies (ray.py:339-369), GAIN_FCH frequencies per lane.
+//   rt2d_gain_kernel      Ray2D.populate_NEW for F frequencies (ray.py:339-369), 1/2/4/8 frequencies per lane.
 //   rt2d_dist_kernel      distance to target from stored trajectories (ray.py:282-287).
 //   rt2d_heatmap_kernel   Simulation2D.heatmap accumulation (simulation.py:120-131, functions.py:12-19):
 //                         one wave per ray, last-write-wins per cell through an LDS hash, f64 atomics into H.
@@ -377,7 +377,6 @@ __global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
 
 // ------------------------------------------------------------------------------------------------------
 // gain (ray.py:339-369)
-#define GAIN_FCH 8
 static __constant__ double k_A1 = 0.106, k_A3 = 0.00049;                  // model_absorption.py:34-35
 #define RT2D_WAVE_HEIGHT_RMS 2.0                                          // preferences.py:11
 #define RT2D_DZ_SEDIMENT 2.0                                              // preferences.py:12
@@ -412,6 +411,7 @@ struct GainArgs {
     double* G; double* G_end;
 };
 
+template <int FCH>
 __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
@@ -419,15 +419,15 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     const double* tab = s_tab;                 // gain-section offsets are relative to gain_off
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n) return;
-    const int f0 = blockIdx.y * GAIN_FCH;
-    const int nf = min(GAIN_FCH, a.n_freqs - f0);
+    const int f0 = blockIdx.y * FCH;
+    const int nf = min(FCH, a.n_freqs - f0);
     const DevTable& ab = a.env.absorb;
     const int np = a.n_pts[r];
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
 
-    double fr[GAIN_FCH], ff[GAIN_FCH], S[GAIN_FCH], A[GAIN_FCH];
+    double fr[FCH], ff[FCH], S[FCH], A[FCH];
 #pragma unroll
-    for (int k = 0; k < GAIN_FCH; ++k) {
+    for (int k = 0; k < FCH; ++k) {
         fr[k] = (k < nf) ? a.freqs[f0 + k] : 1.0;
         double f = fr[k] / 1000;                                           // model_absorption.py:32
         ff[k] = f * f;
@@ -440,11 +440,14 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     double xp = a.X[base], zp = a.Z[base];
     if (a.G) {
 #pragma unroll
-        for (int k = 0; k < GAIN_FCH; ++k) if (k < nf) a.G[(int64_t)(f0 + k) * a.total + base] = 0.0;
+        for (int k = 0; k < FCH; ++k) if (k < nf) a.G[(int64_t)(f0 + k) * a.total + base] = 0.0;
     }
+    double xn = 0.0, zn = 0.0;
+    if (np > 1) { xn = a.X[base + RT2D_WAVE]; zn = a.Z[base + RT2D_WAVE]; }
     for (int s = 1; s < np; ++s) {
         int64_t o = base + (int64_t)s * RT2D_WAVE;
-        double x = a.X[o], z = a.Z[o];
+        double x = xn, z = zn;
+        if (s + 1 < np) { xn = a.X[o + RT2D_WAVE]; zn = a.Z[o + RT2D_WAVE]; }   // next point in flight during this step
         double ddx = x - xp, ddz = z - zp;
         double dL = sqrt(ddx * ddx + ddz * ddz);
         // six depth factors at the START point of the segment (ray.py:346 uses XZ[:-1, 1])
@@ -462,7 +465,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
             if (sediment) Zp0 = rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr);
             else ang = a.reb_angle[kk];
 #pragma unroll
-            for (int k = 0; k < GAIN_FCH; ++k) {
+            for (int k = 0; k < FCH; ++k) {
                 double wavelength = vel / fr[k];
                 double rc = sediment ? rt2d_refcoef_sediment(wavelength, Zp0) : rt2d_refcoef_surface(wavelength, ang);
                 A[k] += 10 * log10(rc);
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
             next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
         }
 #pragma unroll
-        for (int k = 0; k < GAIN_FCH; ++k) {
+        for (int k = 0; k < FCH; ++k) {
             double alpha_1 = k_A1 * (f1 * ff[k]) / (f1s + ff[k]);          // model_absorption.py:37-44
             double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
             double alpha_3 = k_A3 * ff[k];
@@ -484,7 +487,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     }
     if (a.G_end) {
 #pragma unroll
-        for (int k = 0; k < GAIN_FCH; ++k) if (k < nf) a.G_end[(int64_t)(f0 + k) * a.n + r] = S[k] + A[k];
+        for (int k = 0; k < FCH; ++k) if (k < nf) a.G_end[(int64_t)(f0 + k) * a.n + r] = S[k] + A[k];
     }
 }
 
@@ -531,19 +534,93 @@ __device__ __forceinline__ uint32_t rt2d_hash32(uint32_t k) { k ^= k >> 16; k *=
 
 struct HeatArgs {
     const double* X; const double* Z; const double* G; const int64_t* tile_off; const int32_t* n_pts; int64_t n;
-    const int32_t* ray_ids;
+    const uint8_t* ray_mask;                        // n bytes, nonzero = bin this ray (NULL = all)
+    int32_t* work;                                  // [0] = number of rays left to the general kernel, [2 + k] = their ids
     int32_t res_x, res_z; int64_t nx, nz;
     double* H; int64_t* n_dropped; int32_t cap;     // cap: hash slots per ray, power of two
 };
 
+// Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
+// decreases along the path and whose points all fall inside the map can only revisit a cell while it is still in
+// the same column, so "last write wins" reduces to: walk the ray BACKWARDS and deposit the first time a (column,
+// row) pair is seen -- a per-lane bit mask of the rows seen in the current column, no hash.  Rays that fail the
+// forward check (backward-moving rays, points outside the map, which would alias flat indices) are queued for the
+// general kernel below.
+template <int MW>     // 64-bit mask words per lane: rows nz <= 64 * MW
+__global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x / RT2D_WAVE) + (threadIdx.x / RT2D_WAVE);
+    const int lane = threadIdx.x & 63;
+    const int64_t n_tiles = (a.n + RT2D_WAVE - 1) / RT2D_WAVE;
+    if (tile >= n_tiles) return;
+    const int64_t r = tile * RT2D_WAVE + lane;
+    const bool mine = r < a.n && (!a.ray_mask || a.ray_mask[r]);
+    int np = mine ? a.n_pts[r] : 0;
+    const int64_t base = a.tile_off[tile] + lane;
+    int tmax = np;
+    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+
+    // forward check
+    bool ok = true;
+    int64_t prev_ix = INT64_MIN;
+    for (int s = 0; s < tmax; ++s) {
+        if (s < np) {
+            int64_t o = base + (int64_t)s * RT2D_WAVE;
+            int64_t ix = rt2d_floordiv((int64_t)a.X[o], a.res_x);
+            int64_t iz = rt2d_floordiv((int64_t)a.Z[o], -1 * (int64_t)a.res_z);
+            ok = ok && ix >= prev_ix && ix >= 0 && ix < a.nx && iz >= 0 && iz < a.nz;
+            prev_ix = ix;
+        }
+    }
+    if (!ok) {
+        int k = atomicAdd(&a.work[0], 1);
+        a.work[2 + k] = (int32_t)r;
+        np = 0;
+    }
+    tmax = np;
+    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+
+    // backward walk
+    unsigned long long seen[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) seen[w] = 0ull;
+    int64_t cur_ix = -1;
+    for (int s = tmax - 1; s >= 0; --s) {
+        if (s < np) {
+            int64_t o = base + (int64_t)s * RT2D_WAVE;
+            int64_t ix = rt2d_floordiv((int64_t)a.X[o], a.res_x);
+            int64_t iz = rt2d_floordiv((int64_t)a.Z[o], -1 * (int64_t)a.res_z);
+            if (ix != cur_ix) {
+                cur_ix = ix;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) seen[w] = 0ull;
+            }
+            const unsigned long long bit = 1ull << (iz & 63);
+            const int word = (int)(iz >> 6);
+            bool fresh = false;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) if (w == word) { fresh = (seen[w] & bit) == 0; seen[w] |= bit; }
+            if (fresh) {
+                double tmult = pow(10.0, a.G[o] / 10);                         // ray.py:317
+                double val = pow(tmult, -0.1);                                 // simulation.py:129
+                atomicAdd(&a.H[ix * a.nz + iz], val);
+            }
+        }
+    }
+}
+
+
 __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
-    const int64_t r = a.ray_ids ? (int64_t)a.ray_ids[blockIdx.x] : (int64_t)blockIdx.x;
     const int lane = threadIdx.x;
-    const int np = a.n_pts[r];
-    const int64_t base = a.tile_off[r >> 6] + (r & 63);
     const int64_t size = a.nx * a.nz;
     const uint32_t mask = (uint32_t)a.cap - 1;
+    // rays come either from the queue the fast kernel filled (work != NULL) or straight from the mask
+    const int64_t n_items = a.work ? (int64_t)a.work[0] : a.n;
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
+    if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
 
     // pass 0: count run ends (candidates) and dropped points
     int n_cand = 0, n_drop = 0;
@@ -603,6 +680,7 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
             }
         }
         __syncthreads();
+    }
     }
 }
 
@@ -858,10 +936,13 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     a.rebound_cap = rebound_cap; a.n = n; a.freqs = freqs; a.n_freqs = n_freqs; a.total = total; a.G = G; a.G_end = G_end;
     const size_t lds = (size_t)env->dev.gain_doubles * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain: absorption tables do not fit in LDS");
-    HIP_OK(hipFuncSetAttribute((const void*)rt2d_gain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int block = (n <= 64 * 512) ? 64 : 256;
-    dim3 grid((unsigned)((n + block - 1) / block), (unsigned)((n_freqs + GAIN_FCH - 1) / GAIN_FCH));
-    hipLaunchKernelGGL(rt2d_gain_kernel, grid, dim3(block), lds, (hipStream_t)stream, a);
+    const int fch = n_freqs >= 8 ? 8 : (n_freqs >= 3 ? 4 : n_freqs);      // frequencies per lane: amortises the 6 table evals
+    dim3 grid((unsigned)((n + block - 1) / block), (unsigned)((n_freqs + fch - 1) / fch));
+    void (*kern)(const GainArgs) = fch == 8 ? rt2d_gain_kernel<8> : fch == 4 ? rt2d_gain_kernel<4>
+                                  : fch == 2 ? rt2d_gain_kernel<2> : rt2d_gain_kernel<1>;
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -878,9 +959,10 @@ int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, con
 }
 
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
-                                const int32_t* n_pts, int64_t n, const int32_t* ray_ids, int64_t n_sel,
+                                const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                 const int32_t* res, const int32_t* shape,
-                                double* H, int64_t* n_dropped, void* stream) {
+                                double* H, int64_t* n_dropped, int32_t* work, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (!X || !Z || !G || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
     if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
     if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
@@ -888,12 +970,23 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     if (n > 0x7fffffff) return fail("rt2d_heatmap_accumulate: too many rays for one launch");
     HeatArgs a; memset(&a, 0, sizeof a);
     a.X = X; a.Z = Z; a.G = G; a.tile_off = tile_off; a.n_pts = n_pts; a.n = n;
-    a.ray_ids = ray_ids;
-    const int64_t n_launch = ray_ids ? n_sel : n;
-    if (n_launch <= 0) return n_launch == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative selection size");
+    a.ray_mask = ray_mask;
     a.res_x = res[0]; a.res_z = res[1]; a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
     a.cap = 4096;
-    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)n_launch), dim3(RT2D_WAVE), (size_t)a.cap * 8, (hipStream_t)stream, a);
+    const bool fast = work != nullptr && shape[1] <= 256;
+    if (fast) {
+        a.work = work;
+        HIP_OK(hipMemsetAsync(work, 0, 2 * sizeof(int32_t), stream));
+        const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+        const int wpb = (n_tiles <= 1024) ? 1 : 4;
+        const unsigned blocks = (unsigned)((n_tiles + wpb - 1) / wpb);
+        if (shape[1] <= 64) hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<1>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        else hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<4>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        HIP_OK(hipGetLastError());
+    }
+    // general kernel: everything (no workspace) or what the fast kernel queued; blocks stride over the items
+    const int64_t blocks = n < 16384 ? n : 16384;
+    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(RT2D_WAVE), (size_t)a.cap * 8, stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

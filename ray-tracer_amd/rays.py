@@ -245,8 +245,9 @@ class RayFan:
         return out
 
     # -- heat map (simulation.py:120-131) ---------------------------------------------------------
-    def heatmap_accumulate(self, H, res, shape, freq=1, ray_ids=None, dropped=None):
-        """Adds this fan's rays (or the subset ray_ids, a device int32 tensor) into H (nx*nz, device f64)."""
+    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True):
+        """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
+        fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests)."""
         self._need_store()
         torch = _torch()
         L = _lib.lib()
@@ -255,11 +256,12 @@ class RayFan:
         with torch.cuda.device(self.device):
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
-            n_sel = 0 if ray_ids is None else int(ray_ids.shape[0])
+            work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device) if fast else None
             _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
                                                  self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
-                                                 _ptr(ray_ids), n_sel, res_c, shape_c, H.data_ptr(), _ptr(dropped),
+                                                 _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),
                                                  torch.cuda.current_stream().cuda_stream))
+            self.last_slow_rays = int(work[0].item()) if (fast and shape[1] <= 256) else self.n
 
 
 class _LinearPath:

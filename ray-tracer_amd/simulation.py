@@ -85,10 +85,11 @@ class Simulation2D:
         H = torch.zeros(int(shape[0]) * int(shape[1]), dtype=torch.float64, device=device)
         dropped = torch.zeros(1, dtype=torch.int64, device=device)
         for fan, idx in segs:
-            ids = None
+            mask = None
             if len(idx) != fan.n:
-                ids = torch.as_tensor(np.asarray(idx, dtype=np.int32), device=device)
-            fan.heatmap_accumulate(H, res, shape, freq=freq, ray_ids=ids, dropped=dropped)
+                mask = torch.zeros(fan.n, dtype=torch.uint8, device=device)
+                mask[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=device)] = 1
+            fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True))
         return H.view(int(shape[0]), int(shape[1])), dropped
 
     def heatmap(self, **kwargs):

@@ -1,0 +1,35 @@
+"""GPU: sweep + refine (EigenraySim2D scan / refine) against the reference's own run (tests/golden/c5_eigen.npz)."""
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scan_and_refine_vs_reference(rt):
+    g = common.load('c5_eigen')
+    env = common.product_env(rt, g)
+    sim = rt.EigenraySim2D(env, g['source'], g['target'], int(g['n_rays']), int(g['n_rebounds_max']),
+                           n_rays_scan=int(g['n_rays_scan']), scan_angle_min=float(g['scan_angle_min']),
+                           scan_angle_max=float(g['scan_angle_max']), dx_max=float(g['dx_max']), dz_max=float(g['dz_max']))
+    # the sweep: every scanning ray's distance to the target
+    d = sim.scan_fan.host('dist')
+    ref = g['scan_dist']
+    assert np.array_equal(np.isnan(d), np.isnan(ref))
+    m = ~np.isnan(ref)
+    knife = sim.scan_fan.host('margin') <= common.KNIFE_EDGE_M
+    assert np.max(np.abs(d - ref)[m & ~knife]) < 1e-6
+    # selection: same angles, same order (sorted by distance)
+    sel = np.array([r.angle for r in sim.raypacks['scan'].rays])
+    assert np.array_equal(sel, g['scan_selected_angles'])
+    assert abs(sim.dist_avg - float(g['scan_dist_avg'])) < 1e-6
+    sim.refine(iterations=2, n_rays=5)
+    assert sim.n_refines == int(g['n_refines'])
+    for it in range(1, sim.n_refines + 1):
+        got = np.array([r.angle for r in sim.raypacks[f'refine-{it}'].rays])
+        assert np.allclose(got, g[f'refine{it}_angles'], rtol=0, atol=1e-15), it
+        gd = np.array([r.dist_to_target for r in sim.raypacks[f'refine-{it}'].rays])
+        assert np.max(np.abs(gd - g[f'refine{it}_dist'])) < 1e-6
+    assert abs(sim.dist_avg - float(g['final_dist_avg'])) < 1e-6

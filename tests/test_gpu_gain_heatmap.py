@@ -118,15 +118,18 @@ def test_gain_vs_oracle_same_points(rt, orc):
     assert worst < 1e-11
 
 
+@pytest.mark.parametrize('fast', [True, False])
 @pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
-def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name):
-    """Binning in isolation: oracle heat map over the GPU's own points and gains -> every cell equal to 1e-12."""
+def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
+    """Binning in isolation: oracle heat map over the GPU's own points and gains -> every cell equal to 1e-12.
+    fast=True: coalesced tile kernel + general kernel for the queued rays; fast=False: general kernel only."""
     g = common.load(name)
     fan, env = _cast(rt, g)
     oenv = common.oracle_env_from_product(orc, env)
     sim = rt.Simulation2D(env, g['fan_source'])
     sim.raypacks['main'].add_fan(fan)
-    H, dropped = sim.heatmap_full(resolution=[50, 25])
+    H, dropped = sim.heatmap_full(resolution=[50, 25], fast=fast)
+    print(f'{name}: fast={fast}: {fan.last_slow_rays} of {fan.n} rays went through the general kernel')
     H = H.cpu().numpy()
     rays = [r for r in _oracle_rays_from_fan(orc, rt, fan) if r.status == 0]
     for r in rays:
@@ -138,7 +141,7 @@ def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name):
     rel = np.abs(H - Href) / np.maximum(1e-300, np.abs(Href))
     assert rel[Href != 0].max() < 1e-12
     for cutoff in (.02, .1, .5):
-        out = sim.heatmap(resolution=[50, 25], cutoff=cutoff, reduction_power=.5)
+        out = sim.heatmap(resolution=[50, 25], cutoff=cutoff, reduction_power=.5, fast=fast)
         _, plot_ref, _ = orc.heatmap(oenv, rays, res=(50, 25), cutoff=cutoff)
         assert out.shape == plot_ref.shape
         assert np.abs(out - plot_ref).max() < 1e-12
@@ -184,3 +187,51 @@ def test_heatmap_vs_reference(rt, name):
     assert n_bad <= 0.02 * H.size
     # the mass of the map moves by at most ~one deposit per edge point (a flip can merge two cells of one ray)
     assert abs(H.sum() - ref.sum()) <= 1e-9 * ref.sum() + 2.0 * int(edge.sum())
+
+
+def test_heatmap_backward_and_out_of_map_rays(rt, orc):
+    """Rays that turn back (x decreases) or leave the map cannot use the column-monotone fast kernel: they are
+    queued for the general kernel, and the result still equals the oracle's in every cell."""
+    xs = np.linspace(0., 20000., 401)
+    zs = np.where(xs < 9000., -900., -900. + (xs - 9000.) * 0.9)            # a steep wall turns rays back
+    zs = np.minimum(zs, -20.)
+    rmin, rmax = np.array([0., -1001.]), np.array([20000., 1.])
+    env = rt.Environment2D((xs, zs), (np.array([0., 20000.]), np.array([0., 0.])), rmin, rmax)
+    oenv = common.oracle_env_from_product(orc, env)
+    angles = np.linspace(-0.6, 0.2, 130)
+    fan = rt.RayFan(env, np.array([0., -40.]), angles, dx_max=50., dz_max=25., n_rebounds_max=12)
+    X, Z, valid = fan.padded_host()
+    went_back = (np.diff(np.where(valid, X, np.inf), axis=1) < 0).any(axis=1)
+    assert went_back.sum() >= 5, 'fixture must contain rays that move backwards'
+    sim = rt.Simulation2D(env, np.array([0., -40.]))
+    sim.raypacks['main'].add_fan(fan)
+    rays = [r for r in common.oracle_rays_from_fan(orc, rt, fan) if r.status == 0]
+    for r in rays:
+        orc.post_ray(oenv, r)
+    for res in ([50, 25], [50, 7]):          # nz = 41 (one mask word) and nz = 145 (four mask words)
+        Href, _, drop_ref = orc.heatmap(oenv, rays, res=tuple(res))
+        for fast in (True, False):
+            H, dropped = sim.heatmap_full(resolution=res, fast=fast)
+            H = H.cpu().numpy()
+            assert H.shape == Href.shape and int(dropped.item()) == drop_ref
+            assert np.array_equal(H == 0, Href == 0)
+            assert (np.abs(H - Href) / np.maximum(1e-300, np.abs(Href)))[Href != 0].max() < 1e-12
+        assert fan.last_slow_rays == fan.n            # fast=False last
+    H, _ = sim.heatmap_full(resolution=[50, 25], fast=True)
+    assert 0 < fan.last_slow_rays < fan.n
+    # a deliberately small map: points outside are dropped (the reference would raise IndexError) and counted
+    Hs = np.zeros(100 * 41)
+    import torch
+    Hd = torch.zeros(100 * 41, dtype=torch.float64, device=fan.device)
+    dr = torch.zeros(1, dtype=torch.int64, device=fan.device)
+    fan.heatmap_accumulate(Hd, [50, 25], [100, 41], dropped=dr)
+    L = orc.lib()
+    res_c, shape_c = np.array([50, 25], dtype=np.int32), np.array([100, 41], dtype=np.int32)
+    nd = 0
+    for r in common.oracle_rays_from_fan(orc, rt, fan):
+        orc.post_ray(oenv, r)
+        G = orc.gain(oenv, r, 1)
+        Xc, Zc = np.ascontiguousarray(r.XZ[:, 0]), np.ascontiguousarray(r.XZ[:, 1])
+        nd += L.orc_heatmap_add(orc._dp(Xc), orc._dp(Zc), orc._dp(G), r.steps, orc._ip(res_c), orc._ip(shape_c), orc._dp(Hs))
+    assert int(dr.item()) == nd and nd > 0
+    assert np.abs(Hd.cpu().numpy() - Hs).max() <= 1e-12 * Hs.max()
