@@ -186,9 +186,11 @@ int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, con
  * shape: host, 2 ints (nx, nz).  H: device, nx*nz doubles row-major [ix*nz + iz], accumulated into
  * (caller zeroes it).  n_dropped (device int64, may be NULL, caller zeroes it) counts points whose flat index
  * falls outside [-nx*nz, nx*nz) -- the reference raises IndexError there.
- * work: device workspace of n + 2 int32 (contents irrelevant on entry), or NULL.  With a workspace and nz <= 256,
- * rays that only move forward in x and stay inside the map are binned by a coalesced one-wave-per-tile kernel and
- * only the remaining rays go through the general one-wave-per-ray hash kernel; without it every ray does. */
+ * work: device workspace of n + 2 int32 (contents irrelevant on entry), or NULL.  With a workspace, nz <= 256 and
+ * more than 16384 rays (env RT2D_HEATMAP_FAST_MIN_RAYS overrides), rays that only move forward in x and stay inside
+ * the map are binned by a coalesced one-wave-per-tile kernel and only the remaining rays go through the general
+ * one-wave-per-ray hash kernel; otherwise every ray does.  On return work[0] = number of rays the general kernel
+ * handled after the tile kernel, or -1 if the tile kernel was not used. */
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                 const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                 const int32_t* res, const int32_t* shape,

@@ -17,6 +17,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -546,6 +547,7 @@ struct HeatArgs {
 // row) pair is seen -- a per-lane bit mask of the rows seen in the current column, no hash.  Rays that fail the
 // forward check (backward-moving rays, points outside the map, which would alias flat indices) are queued for the
 // general kernel below.
+#define HM_UNROLL 4
 template <int MW>     // 64-bit mask words per lane: rows nz <= 64 * MW
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x / RT2D_WAVE) + (threadIdx.x / RT2D_WAVE);
@@ -559,16 +561,26 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     int tmax = np;
     for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
 
-    // forward check
+    // forward check, HM_UNROLL rows in flight per lane
     bool ok = true;
     int64_t prev_ix = INT64_MIN;
-    for (int s = 0; s < tmax; ++s) {
-        if (s < np) {
-            int64_t o = base + (int64_t)s * RT2D_WAVE;
-            int64_t ix = rt2d_floordiv((int64_t)a.X[o], a.res_x);
-            int64_t iz = rt2d_floordiv((int64_t)a.Z[o], -1 * (int64_t)a.res_z);
-            ok = ok && ix >= prev_ix && ix >= 0 && ix < a.nx && iz >= 0 && iz < a.nz;
-            prev_ix = ix;
+    for (int s0 = 0; s0 < tmax; s0 += HM_UNROLL) {
+        double xs[HM_UNROLL], zs[HM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HM_UNROLL; ++u) {
+            const int s = s0 + u;
+            const int64_t o = base + (int64_t)s * RT2D_WAVE;
+            xs[u] = (s < np) ? a.X[o] : 0.0;
+            zs[u] = (s < np) ? a.Z[o] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HM_UNROLL; ++u) {
+            if (s0 + u < np) {
+                int64_t ix = rt2d_floordiv((int64_t)xs[u], a.res_x);
+                int64_t iz = rt2d_floordiv((int64_t)zs[u], -1 * (int64_t)a.res_z);
+                ok = ok && ix >= prev_ix && ix >= 0 && ix < a.nx && iz >= 0 && iz < a.nz;
+                prev_ix = ix;
+            }
         }
     }
     if (!ok) {
@@ -584,30 +596,61 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
 #pragma unroll
     for (int w = 0; w < MW; ++w) seen[w] = 0ull;
     int64_t cur_ix = -1;
-    for (int s = tmax - 1; s >= 0; --s) {
-        if (s < np) {
-            int64_t o = base + (int64_t)s * RT2D_WAVE;
-            int64_t ix = rt2d_floordiv((int64_t)a.X[o], a.res_x);
-            int64_t iz = rt2d_floordiv((int64_t)a.Z[o], -1 * (int64_t)a.res_z);
-            if (ix != cur_ix) {
-                cur_ix = ix;
+    for (int s0 = tmax - 1; s0 >= 0; s0 -= HM_UNROLL) {
+        double xs[HM_UNROLL], zs[HM_UNROLL], gs[HM_UNROLL];
 #pragma unroll
-                for (int w = 0; w < MW; ++w) seen[w] = 0ull;
-            }
-            const unsigned long long bit = 1ull << (iz & 63);
-            const int word = (int)(iz >> 6);
+        for (int u = 0; u < HM_UNROLL; ++u) {
+            const int s = s0 - u;
+            const int64_t o = base + (int64_t)s * RT2D_WAVE;
+            const bool live = s >= 0 && s < np;
+            xs[u] = live ? a.X[o] : 0.0;
+            zs[u] = live ? a.Z[o] : 0.0;
+            gs[u] = live ? a.G[o] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < HM_UNROLL; ++u) {
+            const int s = s0 - u;
             bool fresh = false;
+            int64_t cell = -1 - lane;                       // unique per lane: never merges
+            double val = 0.0;
+            if (s >= 0 && s < np) {
+                int64_t ix = rt2d_floordiv((int64_t)xs[u], a.res_x);
+                int64_t iz = rt2d_floordiv((int64_t)zs[u], -1 * (int64_t)a.res_z);
+                if (ix != cur_ix) {
+                    cur_ix = ix;
 #pragma unroll
-            for (int w = 0; w < MW; ++w) if (w == word) { fresh = (seen[w] & bit) == 0; seen[w] |= bit; }
-            if (fresh) {
-                double tmult = pow(10.0, a.G[o] / 10);                         // ray.py:317
-                double val = pow(tmult, -0.1);                                 // simulation.py:129
-                atomicAdd(&a.H[ix * a.nz + iz], val);
+                    for (int w = 0; w < MW; ++w) seen[w] = 0ull;
+                }
+                const unsigned long long bit = 1ull << (iz & 63);
+                const int word = (int)(iz >> 6);
+#pragma unroll
+                for (int w = 0; w < MW; ++w) if (w == word) { fresh = (seen[w] & bit) == 0; seen[w] |= bit; }
+                if (fresh) {
+                    double tmult = pow(10.0, gs[u] / 10);                      // ray.py:317
+                    val = pow(tmult, -0.1);                                    // simulation.py:129
+                    cell = ix * a.nz + iz;
+                }
+            }
+            // Neighbouring lanes are neighbouring angles: at one step they mostly sit in the same cell.  Sum runs of
+            // equal cells across the wave (segmented scan) and let the last lane of each run issue ONE atomic.
+            if (__any(fresh)) {
+                const int c32 = (int)cell;
+                const int c_prev = __shfl_up(c32, 1);
+                const bool head = (lane == 0) || (c_prev != c32);
+                const unsigned long long heads = __ballot(head);
+                const int run = __popcll(heads & (~0ull >> (63 - lane)));   // run index: equal <=> same run of equal cells
+#pragma unroll
+                for (int off = 1; off < RT2D_WAVE; off <<= 1) {
+                    double v_up = __shfl_up(val, off);
+                    int run_up = __shfl_up(run, off);
+                    if (lane >= off && run_up == run) val += v_up;
+                }
+                const bool tail = (lane == RT2D_WAVE - 1) || ((heads >> (lane + 1)) & 1ull);
+                if (fresh && tail) atomicAdd(&a.H[cell], val);
             }
         }
     }
 }
-
 
 __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
@@ -973,7 +1016,11 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     a.ray_mask = ray_mask;
     a.res_x = res[0]; a.res_z = res[1]; a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
     a.cap = 4096;
-    const bool fast = work != nullptr && shape[1] <= 256;
+    // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
+    // below ~16k rays the latter finishes first
+    static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 16384;
+    const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays;
+    if (work && !fast) HIP_OK(hipMemsetAsync(work, 0xff, sizeof(int32_t), stream));     // work[0] = -1: every ray went general
     if (fast) {
         a.work = work;
         HIP_OK(hipMemsetAsync(work, 0, 2 * sizeof(int32_t), stream));

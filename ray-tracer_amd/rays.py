@@ -261,7 +261,8 @@ class RayFan:
                                                  self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
                                                  _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),
                                                  torch.cuda.current_stream().cuda_stream))
-            self.last_slow_rays = int(work[0].item()) if (fast and shape[1] <= 256) else self.n
+            queued = int(work[0].item()) if fast else -1
+            self.last_slow_rays = self.n if queued < 0 else queued      # rays binned by the general kernel
 
 
 class _LinearPath:

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# exercise the coalesced heat-map tile kernel on the small test fans too (default threshold: 16384 rays)
+os.environ.setdefault('RT2D_HEATMAP_FAST_MIN_RAYS', '0')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
