@@ -52,7 +52,7 @@ RES = (50, 25)
 class Stages:
     """HIP-event timing of the device stages of one step (events on torch's current stream, which is the
     stream every rt2d_* launch uses)."""
-    NAMES = ('cast_count', 'layout', 'cast_store', 'gain', 'heatmap', 'finalize')
+    NAMES = ('cast_count', 'layout', 'cast_store', 'layout_compact', 'gain', 'heatmap', 'finalize')
 
     def __init__(self, torch):
         self.torch = torch
@@ -90,29 +90,56 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     p.dx_max, p.dz_max, p.n_steps_max, p.n_rebounds_max, p.backprop = PROP['dx_max'], PROP['dz_max'], 100000, PROP['n_rebounds_max'], 1
     cap = PROP['n_rebounds_max'] + 1
     p.rebound_cap = cap
-    if ev: ev[0].record()
-    _lib.check(L.rt2d_cast_count(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(out), stream))
-    if ev: ev[1].record()
+    out.reb_step = None
     n_tiles = (n + 63) // 64
     tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=device)
     total = C.c_int64(0)
-    _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), C.byref(total), stream))
-    total = int(total.value)
-    if ev: ev[2].record()
-    X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
     reb_step = torch.empty((cap, n), **i32)
     reb_surface = torch.empty((cap, n), dtype=torch.uint8, device=device)
     reb_vel, reb_ang, reb_px, reb_pz = (torch.empty((cap, n), **f64) for _ in range(4))
-    out.reb_step, out.reb_surface, out.reb_velocity = reb_step.data_ptr(), reb_surface.data_ptr(), reb_vel.data_ptr()
-    out.reb_angle, out.reb_pos_x, out.reb_pos_z = reb_ang.data_ptr(), reb_px.data_ptr(), reb_pz.data_ptr()
-    _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(out),
-                                 tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(), None, stream))
-    if ev: ev[3].record()
+
+    def with_log(o):
+        o.reb_step, o.reb_surface, o.reb_velocity = reb_step.data_ptr(), reb_surface.data_ptr(), reb_vel.data_ptr()
+        o.reb_angle, o.reb_pos_x, o.reb_pos_z = reb_ang.data_ptr(), reb_px.data_ptr(), reb_pz.data_ptr()
+        return o
+
+    room = 4096
+    speculative = n_tiles * room * 64 * 16 <= (1 << 30)          # same policy as RayFan (ray-tracer_amd/rays.py)
+    done = False
+    if ev: ev[0].record()
+    if speculative:
+        # small fan: one storing pass into a provisional layout, exact layout, compaction copy
+        if ev: ev[1].record(); ev[2].record()
+        off0 = torch.arange(n_tiles + 1, dtype=torch.int64, device=device) * (room * 64)
+        X0, Z0 = torch.empty(n_tiles * room * 64, **f64), torch.empty(n_tiles * room * 64, **f64)
+        _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(with_log(out)),
+                                     off0.data_ptr(), X0.data_ptr(), Z0.data_ptr(), None, stream))
+        if ev: ev[3].record()
+        _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), C.byref(total), stream))
+        if int(tile_off.diff().max().item()) <= room * 64 and not bool((status == -2).any().item()):
+            total = int(total.value)
+            X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
+            _lib.check(L.rt2d_traj_compact(off0.data_ptr(), tile_off.data_ptr(), n, X0.data_ptr(), Z0.data_ptr(), None,
+                                           X.data_ptr(), Z.data_ptr(), None, stream))
+            done = True
+    if not done:
+        cnt = _lib.Rt2dRayOut()
+        cnt.n_pts, cnt.n_rebounds = n_pts.data_ptr(), nreb.data_ptr()
+        _lib.check(L.rt2d_cast_count(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(cnt), stream))
+        if ev: ev[1].record()
+        _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), C.byref(total), stream))
+        total = int(total.value)
+        if ev: ev[2].record()
+        X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
+        _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(with_log(out)),
+                                     tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(), None, stream))
+        if ev: ev[3].record()
+    if ev: ev[4].record()
     G = torch.empty(total, **f64)
     freq = torch.ones(1, **f64)
     _lib.check(L.rt2d_gain(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap, n,
                            freq.data_ptr(), 1, total, G.data_ptr(), None, stream))
-    if ev: ev[4].record()
+    if ev: ev[5].record()
     # plot range of the rays that did not fail (RayPack2D.add fold, origin included) -> heat-map shape
     okm = (status == 0)
     big = torch.finfo(torch.float64).max
@@ -131,11 +158,11 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
                                          mask.data_ptr(), res_c, shape_c, H.data_ptr(), None, work.data_ptr(), stream))
     if collectives:
         parallel.allreduce_heatmap(H)                                          # C2
-    if ev: ev[5].record()
+    if ev: ev[6].record()
     outp = torch.empty(int(shape[0]) * int(shape[1]), **f64)
     scratch = torch.empty(2, **f64)
     _lib.check(L.rt2d_heatmap_finalize(H.data_ptr(), shape_c, .02, .5, outp.data_ptr(), scratch.data_ptr(), stream))
-    if ev: ev[6].record()
+    if ev: ev[7].record()
     return total, n_pts, status, outp.view(int(shape[1]), int(shape[0]))
 
 

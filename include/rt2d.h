@@ -153,11 +153,21 @@ int32_t rt2d_cast_count(rt2d_env_t env, const double* angles, int64_t n, const d
 int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int64_t* total_out, void* stream);
 
 /* Same propagation, storing every point (reference: the np.insert at ray.py:192,216,236) in tile layout.
- * C (device, may be NULL) additionally receives the sound speed at every point (ray.py:273). */
+ * C (device, may be NULL) additionally receives the sound speed at every point (ray.py:273).
+ * A tile never writes outside [tile_off[t], tile_off[t+1]): points beyond the tile's room are counted in n_pts but
+ * not stored.  This allows a single speculative pass over a provisional layout (e.g. the same generous room for
+ * every tile) followed by rt2d_traj_layout + rt2d_traj_compact when max(n_pts) fits, instead of count + store. */
 int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const double* src,
                         const Rt2dParams* params, const double* init_slope, const double* init_mult,
                         const Rt2dRayOut* out, const int64_t* tile_off, double* X, double* Z, double* C,
                         void* stream);
+
+/* Copies trajectories from one tile layout to another (typically provisional -> exact); the first
+ * tile_off_dst[t+1]-tile_off_dst[t] elements of every tile are copied.  C_src/C_dst may both be NULL.
+ * No counterpart in the reference (it grows XZ point by point with np.insert). */
+int32_t rt2d_traj_compact(const int64_t* tile_off_src, const int64_t* tile_off_dst, int64_t n,
+                          const double* X_src, const double* Z_src, const double* C_src,
+                          double* X_dst, double* Z_dst, double* C_dst, void* stream);
 
 /* Post-pass arrays in tile layout (reference: ray.py:271-275): L and T are cumulative (value 0 at point 0);
  * dL[s] / dT[s] belong to the segment ending at point s (slot 0 is written as 0). Any output may be NULL. */

@@ -121,25 +121,59 @@ struct TargetTrack {
     }
 };
 
-template <bool WRITE, bool LDS_TABLES>
+// Rarely used launch data (rebound branch, final stores) is parked in LDS instead of scalar registers: the hot
+// loop alone needs ~90 SGPRs of table descriptors and bounds, and everything beyond the budget would be spilled
+// to v_writelane/v_readlane pairs inside the loop.
+struct CastCold {
+    DevTable dx_floor, dx_ceil;
+    Rt2dRayOut out;
+    int64_t n;
+    int32_t rebound_cap, n_rebounds_max;
+};
+
+// which side of the bounds a (possibly clipped) point leaves through: the value fit_to_bounds returns (ray.py:84-107)
+__device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, double x_new, double z_prev, double z_new, double dx_z) {
+    int out = 0;
+    if (x_new < e.range_min[0]) { x_new = e.range_min[0]; z_new = -1 * dx_z * (x_new - x_prev) + z_prev; out = 1; }
+    else if (x_new > e.range_max[0]) { x_new = e.range_max[0]; z_new = dx_z * (x_new - x_prev) + z_prev; out = 2; }
+    if (z_new < e.range_min[1]) out = 3; else if (z_new > e.range_max[1]) out = 4;
+    return out;
+}
+
+// WRITE: store the trajectory.  LDS_TABLES: step section of the blob staged in LDS.  POST: also produce the scalar
+// post-pass (L, T, range, target products, decision margin); the counting pass of a stored cast does not need it.
+template <bool WRITE, bool LDS_TABLES, bool POST>
 __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    extern __shared__ __attribute__((aligned(16))) double s_mem[];
+    constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
+    CastCold* cold = reinterpret_cast<CastCold*>(s_mem);
+    double* s_tab = s_mem + ((COLD_DOUBLES + 1) & ~1);
+    if (threadIdx.x == 0) {
+        cold->dx_floor = a.env.dx_floor; cold->dx_ceil = a.env.dx_ceil; cold->out = a.out; cold->n = a.n;
+        cold->rebound_cap = a.p.rebound_cap; cold->n_rebounds_max = a.p.n_rebounds_max;
+    }
     const double* tab;
     if (LDS_TABLES) {
         for (int i = threadIdx.x; i < a.env.step_doubles; i += blockDim.x) s_tab[i] = a.blob[i];
-        __syncthreads();
         tab = s_tab;
     } else {
         tab = a.blob;
     }
+    __syncthreads();
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n) return;
     const DevEnv& e = a.env;
     const Rt2dParams& p = a.p;
-    const int64_t n = a.n;
 
-    int64_t base = 0;
-    if (WRITE) base = a.tile_off[r >> 6] + (r & 63);
+    // trajectory slot of this lane: pointer to its current point, and how many points its tile has room for
+    double* px = nullptr; double* pz = nullptr; double* pc = nullptr;
+    int room = 0;
+    if (WRITE) {
+        const int64_t t0 = a.tile_off[r >> 6], t1 = a.tile_off[(r >> 6) + 1];
+        room = (int)((t1 - t0) / RT2D_WAVE);
+        px = a.X + t0 + (r & 63); pz = a.Z + t0 + (r & 63);
+        if (a.C) pc = a.C + t0 + (r & 63);
+    }
 
     int status = RT2D_RAY_OK, stop = RT2D_STOP_NONE, n_reb = 0, n_pts = 1;
     double x = a.src_x, z = a.src_z;
@@ -159,40 +193,42 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     double x_dir = 1.0, kx = x_dir, kz = dx_z;
 
     // post-pass state (ray.py:263-279)
-    int jz = rt2d_piece(tab, e.cz, z);
-    double c_pt = rt2d_quad_at(tab, e.cz, jz, z - tab[e.cz.off_breaks + jz], 0);   // C[0] = calc_c(z0), ray.py:273
-    double L = 0.0, T = 0.0;
+    double c_pt = 0.0, L = 0.0, T = 0.0;
     double min_x = x, max_x = x, min_z = z, max_z = z;
     double margin = INFINITY;
-    const bool has_target = p.has_target != 0;
+    const bool has_target = POST && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
-    TargetTrack tt; tt.init();
-    if (has_target) tt.add(x, z, 0.0, 0, tx);
-    if (WRITE) { a.X[base] = x; a.Z[base] = z; if (a.C) a.C[base] = c_pt; }
+    TargetTrack tt;
+    if (POST || WRITE) {
+        int jz = rt2d_piece(tab, e.cz, z);
+        c_pt = rt2d_quad_at(tab, e.cz, jz, z - tab[e.cz.off_breaks + jz], 0);       // C[0] = calc_c(z0), ray.py:273
+    }
+    if (POST) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
+    if (WRITE && room > 0) { *px = x; *pz = z; if (pc) *pc = c_pt; }
 
     for (int i = 0; i < p.n_steps_max; ++i) {
         // step sizing (ray.py:153-154)
         if (fabs(dx_z) > dx_z_max) { double s = p.dz_max / fabs(dx_z); kx *= s; kz *= s; }
         else { kx *= p.dx_max; kz *= p.dx_max; }
         double x_new = x + kx, z_new = z + kz;                            // ray.py:157
-        margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+        if (POST) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
 
-        {   // horizontal bounds first (ray.py:162-167); the clipped point is NOT appended
-            double xt = x_new, zt = z_new;
-            int out = rt2d_fit(e, x, xt, z, zt, dx_z, x_dir);
+        // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
+        // clipped in x is still inside in z; the clipped point is NOT appended
+        if (x_new < e.range_min[0] || x_new > e.range_max[0]) {
+            int out = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
             if (out == 1 || out == 2) { stop = out; break; }
         }
 
         const double z_floor = rt2d_eval_lin(tab, e.floor, x_new);        // ray.py:172-173
         const double z_ceil = rt2d_eval_lin(tab, e.ceil, x_new);
-        margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
+        if (POST) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
 
         const bool hit_floor = z_new < z_floor;
         const bool hit_ceil = !hit_floor && (z_new > z_ceil);
         if (hit_floor || hit_ceil) {                                      // ray.py:176-220
-            const DevTable& surf = hit_floor ? e.floor : e.ceil;
-            const DevTable& slope_t = hit_floor ? e.dx_floor : e.dx_ceil;
-            double fx = rt2d_eval_lin(tab, surf, x);
+            const DevTable slope_t = hit_floor ? cold->dx_floor : cold->dx_ceil;
+            double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : rt2d_eval_lin(tab, e.ceil, x);
             x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
             z_new = hit_floor ? z_floor : z_ceil;
             bool ok;
@@ -206,33 +242,38 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             kx = rx; kz = rz;
             double q = kz / kx;
             double ang = 1 / sqrt(1 + q * q);                              // ray.py:184,207 (cos of grazing angle)
-            if (n_reb < p.rebound_cap) {
-                int64_t k = (int64_t)n_reb * n + r;
-                if (a.out.reb_step) a.out.reb_step[k] = i + 1;
-                if (a.out.reb_surface) a.out.reb_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
-                if (a.out.reb_velocity) a.out.reb_velocity[k] = c;
-                if (a.out.reb_angle) a.out.reb_angle[k] = ang;
-                if (a.out.reb_pos_x) a.out.reb_pos_x[k] = x;
-                if (a.out.reb_pos_z) a.out.reb_pos_z[k] = z;
-            } else if (a.out.reb_step) {
+            const Rt2dRayOut& co = cold->out;
+            if (n_reb < cold->rebound_cap) {
+                int64_t k = (int64_t)n_reb * cold->n + r;
+                if (co.reb_step) co.reb_step[k] = i + 1;
+                if (co.reb_surface) co.reb_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+                if (co.reb_velocity) co.reb_velocity[k] = c;
+                if (co.reb_angle) co.reb_angle[k] = ang;
+                if (co.reb_pos_x) co.reb_pos_x[k] = x;
+                if (co.reb_pos_z) co.reb_pos_z[k] = z;
+            } else if (co.reb_step) {
                 status = RT2D_RAY_ERR_REBOUND_LOG;
             }
             n_reb += 1;
-            margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
-            if (p.n_rebounds_max > -1 && n_reb > p.n_rebounds_max) {       // ray.py:189-195: the point IS appended
+            if (POST) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+            const int nrm = cold->n_rebounds_max;
+            if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended
                 rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);
-                double ddx = x_new - x, ddz = z_new - z;
-                double dL = sqrt(ddx * ddx + ddz * ddz);
-                L += dL; T += dL / c_pt;
-                min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
-                min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
-                if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
-                if (WRITE) {
-                    int64_t o = base + (int64_t)n_pts * RT2D_WAVE;
-                    a.X[o] = x_new; a.Z[o] = z_new;
-                    if (a.C) {
+                if (POST) {
+                    double ddx = x_new - x, ddz = z_new - z;
+                    double dL = sqrt(ddx * ddx + ddz * ddz);
+                    L += dL; T += dL / c_pt;
+                    min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
+                    min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
+                    if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
+                }
+                if (WRITE && n_pts < room) {
+                    px += RT2D_WAVE; pz += RT2D_WAVE;
+                    *px = x_new; *pz = z_new;
+                    if (pc) {
+                        pc += RT2D_WAVE;
                         int j = rt2d_piece(tab, e.cz, z_new);
-                        a.C[o] = rt2d_quad_at(tab, e.cz, j, z_new - tab[e.cz.off_breaks + j], 0);
+                        *pc = rt2d_quad_at(tab, e.cz, j, z_new - tab[e.cz.off_breaks + j], 0);
                     }
                 }
                 n_pts += 1;
@@ -241,14 +282,14 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             }
         }
 
-        {   // all bounds (ray.py:225-230)
-            double xt = x_new, zt = z_new;
-            int out = rt2d_fit(e, x, xt, z, zt, dx_z, x_dir);
-            if (out) { stop = out; break; }
+        // all bounds (ray.py:225-230): any non-zero code stops, the point is not appended
+        if (x_new < e.range_min[0] || x_new > e.range_max[0] || z_new < e.range_min[1] || z_new > e.range_max[1]) {
+            stop = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
+            if (stop) break;
         }
 
         // accept the point (ray.py:235-247)
-        {
+        if (POST) {
             double ddx = x_new - x, ddz = z_new - z;
             double dL = sqrt(ddx * ddx + ddz * ddz);                       // ray.py:271
             L += dL; T += dL / c_pt;                                       // ray.py:272-275
@@ -258,14 +299,16 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         double d = z - tab[e.cz.off_breaks + j];
         c = rt2d_quad_at(tab, e.cz, j, d, 0);
         double dz_c = rt2d_quad_at(tab, e.cz, j, d, 1);
-        c_pt = c;
-        min_x = fmin(min_x, x); max_x = fmax(max_x, x);
-        min_z = fmin(min_z, z); max_z = fmax(max_z, z);
-        if (has_target) tt.add(x, z, T, n_pts, tx);
-        if (WRITE) {
-            int64_t o = base + (int64_t)n_pts * RT2D_WAVE;
-            a.X[o] = x; a.Z[o] = z;
-            if (a.C) a.C[o] = c;
+        if (POST) {
+            c_pt = c;
+            min_x = fmin(min_x, x); max_x = fmax(max_x, x);
+            min_z = fmin(min_z, z); max_z = fmax(max_z, z);
+            if (has_target) tt.add(x, z, T, n_pts, tx);
+        }
+        if (WRITE && n_pts < room) {
+            px += RT2D_WAVE; pz += RT2D_WAVE;
+            *px = x; *pz = z;
+            if (pc) { pc += RT2D_WAVE; *pc = c; }
         }
         n_pts += 1;
         x_dir = rt2d_sign(kx);
@@ -278,19 +321,22 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         if (i == p.n_steps_max - 1) stop = RT2D_STOP_MAX_ITER;                 // ray.py:257-259
     }
 
-    const Rt2dRayOut& o = a.out;
+    const Rt2dRayOut& o = cold->out;
+    const int64_t n = cold->n;
     if (o.n_pts) o.n_pts[r] = n_pts;
     if (o.stop_code) o.stop_code[r] = stop;
     if (o.n_rebounds) o.n_rebounds[r] = n_reb;
     if (o.status) o.status[r] = status;
-    if (o.range) { o.range[r] = min_x; o.range[n + r] = min_z; o.range[2 * n + r] = max_x; o.range[3 * n + r] = max_z; }
-    if (o.L_end) o.L_end[r] = L;
-    if (o.T_end) o.T_end[r] = T;
-    if (o.margin) o.margin[r] = margin;
-    if (has_target) {
-        if (o.dist_to_target) o.dist_to_target[r] = tt.dist(tx, tz, n_pts, min_x, max_x);
-        if (o.step_target) o.step_target[r] = tt.best_step;
-        if (o.T_target) o.T_target[r] = tt.best_T;
+    if (POST) {
+        if (o.range) { o.range[r] = min_x; o.range[n + r] = min_z; o.range[2 * n + r] = max_x; o.range[3 * n + r] = max_z; }
+        if (o.L_end) o.L_end[r] = L;
+        if (o.T_end) o.T_end[r] = T;
+        if (o.margin) o.margin[r] = margin;
+        if (has_target) {
+            if (o.dist_to_target) o.dist_to_target[r] = tt.dist(tx, tz, n_pts, min_x, max_x);
+            if (o.step_target) o.step_target[r] = tt.best_step;
+            if (o.T_target) o.T_target[r] = tt.best_T;
+        }
     }
 }
 
@@ -327,6 +373,20 @@ __global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     
         __syncthreads();
         if (threadIdx.x == 1023) s_carry += s_part[1023];
         __syncthreads();
+    }
+}
+
+// copy every tile from a provisional (padded) layout into the exact one: within a tile both are [step][lane]
+__global__ void __launch_bounds__(256) rt2d_compact_kernel(const int64_t* off_src, const int64_t* off_dst, int64_t n_tiles,
+                                                           const double* X0, const double* Z0, const double* C0,
+                                                           double* X1, double* Z1, double* C1) {
+    const int64_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const int64_t s0 = off_src[t], d0 = off_dst[t], len = off_dst[t + 1] - d0;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.y * blockDim.x) {
+        X1[d0 + i] = X0[s0 + i];
+        Z1[d0 + i] = Z0[s0 + i];
+        if (C0) C1[d0 + i] = C0[s0 + i];
     }
 }
 
@@ -859,11 +919,17 @@ int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out) {
 #define RT2D_LDS_BUDGET (152 * 1024)
 
 extern "C++" {
-template <bool WRITE>
-static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
+static bool wants_post(const Rt2dRayOut& o) {
+    return o.range || o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin;
+}
+
+template <bool WRITE, bool POST>
+static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
     const int64_t n = a.n;
-    const size_t lds = (size_t)env->dev.step_doubles * sizeof(double);
-    const bool in_lds = lds <= RT2D_LDS_BUDGET;
+    const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
+    const size_t tab_bytes = (size_t)env->dev.step_doubles * sizeof(double);
+    const bool in_lds = cold + tab_bytes <= RT2D_LDS_BUDGET;
+    const size_t lds = cold + (in_lds ? tab_bytes : 0);
     int block;
     if (n <= 64 * 512) block = 64;                  // small fans: one wave per workgroup, spread over all CUs
     else if (!in_lds || lds <= 36 * 1024) block = 256;
@@ -872,14 +938,19 @@ static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream
     const int64_t grid = (n + block - 1) / block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     if (in_lds) {
-        auto k = rt2d_cast_kernel<WRITE, true>;
+        auto k = rt2d_cast_kernel<WRITE, true, POST>;
         HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false>), dim3((unsigned)grid), dim3(block), 0, stream, a);
+        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST>), dim3((unsigned)grid), dim3(block), lds, stream, a);
     }
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+template <bool WRITE>
+static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
+    return wants_post(a.out) ? launch_cast2<WRITE, true>(env, a, stream) : launch_cast2<WRITE, false>(env, a, stream);
 }
 }  // extern "C++"
 
@@ -945,6 +1016,21 @@ int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int
         HIP_OK(hipMemcpyAsync(total_out, tile_off + n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
     }
+    return 0;
+}
+
+int32_t rt2d_traj_compact(const int64_t* tile_off_src, const int64_t* tile_off_dst, int64_t n,
+                          const double* X_src, const double* Z_src, const double* C_src,
+                          double* X_dst, double* Z_dst, double* C_dst, void* stream) {
+    if (!tile_off_src || !tile_off_dst || !X_src || !Z_src || !X_dst || !Z_dst) return fail("rt2d_traj_compact: null argument");
+    if ((C_src == nullptr) != (C_dst == nullptr)) return fail("rt2d_traj_compact: C_src and C_dst go together");
+    if (n <= 0) return n == 0 ? 0 : fail("rt2d_traj_compact: negative ray count");
+    const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+    if (n_tiles > 0x7fffffff) return fail("rt2d_traj_compact: too many tiles");
+    const unsigned split = n_tiles < 512 ? 16 : 1;       // few tiles: several workgroups per tile
+    hipLaunchKernelGGL(rt2d_compact_kernel, dim3((unsigned)n_tiles, split), dim3(256), 0, (hipStream_t)stream,
+                       tile_off_src, tile_off_dst, n_tiles, X_src, Z_src, C_src, X_dst, Z_dst, C_dst);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

@@ -16,11 +16,13 @@ import ctypes as C
 
 import numpy as np
 
-from .preferences import (DX_MAX_DEFAULT, DZ_MAX_DEFAULT, N_STEPS_MAX, N_REBOUNDS_MAX)
+from .preferences import (DX_MAX_DEFAULT, DZ_MAX_DEFAULT, N_STEPS_MAX, N_REBOUNDS_MAX, REBOUND_LOG_CAP_DEFAULT)
 from . import _lib
 from ._lib import STOP_REASONS, RAY_ERR_INTERP
 
 TILE = 64
+SPECULATIVE_ROOM = 4096          # points per ray a speculative single-pass cast reserves
+SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below this
 
 
 def _torch():
@@ -100,48 +102,97 @@ class RayFan:
             self._init = (init_slope, init_mult)
             src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
 
-            out = _lib.Rt2dRayOut()
-            out.n_pts, out.stop_code = self.n_pts.data_ptr(), self.stop_code.data_ptr()
-            out.n_rebounds, out.status = self.n_rebounds.data_ptr(), self.status.data_ptr()
-            out.range, out.L_end, out.T_end = self.range.data_ptr(), self.L_end.data_ptr(), self.T_end.data_ptr()
-            out.margin = self.margin.data_ptr()
-            if self.target is not None:
-                out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
-                out.T_target = self.T_target.data_ptr()
-            # pass 1: count points (and rebounds) without storing anything
-            p = self._params(0)
-            _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
-                                         _ptr(init_mult), C.byref(out), stream))
+            def full_out():
+                out = _lib.Rt2dRayOut()
+                out.n_pts, out.stop_code = self.n_pts.data_ptr(), self.stop_code.data_ptr()
+                out.n_rebounds, out.status = self.n_rebounds.data_ptr(), self.status.data_ptr()
+                out.range, out.L_end, out.T_end = self.range.data_ptr(), self.L_end.data_ptr(), self.T_end.data_ptr()
+                out.margin = self.margin.data_ptr()
+                if self.target is not None:
+                    out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
+                    out.T_target = self.T_target.data_ptr()
+                return out
+
+            def alloc_log(out, cap):
+                self.rebound_cap = cap
+                self.reb_step = torch.full((cap, n), -1, **i32)
+                self.reb_surface = torch.zeros((cap, n), dtype=torch.uint8, device=dev)
+                self.reb_velocity = torch.zeros((cap, n), **f64)
+                self.reb_angle = torch.zeros((cap, n), **f64)
+                self.reb_pos_x = torch.zeros((cap, n), **f64)
+                self.reb_pos_z = torch.zeros((cap, n), **f64)
+                out.reb_step, out.reb_surface = self.reb_step.data_ptr(), self.reb_surface.data_ptr()
+                out.reb_velocity, out.reb_angle = self.reb_velocity.data_ptr(), self.reb_angle.data_ptr()
+                out.reb_pos_x, out.reb_pos_z = self.reb_pos_x.data_ptr(), self.reb_pos_z.data_ptr()
+
+            def cast_write(out, cap, tile_off, X, Z, Cpt):
+                p = self._params(cap)
+                _lib.check(L.rt2d_cast_write(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
+                                             _ptr(init_mult), C.byref(out), tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(),
+                                             _ptr(Cpt), stream))
+
             self.rebound_cap = 0
             self.tile_off = self.X = self.Z = self.Cpt = None
             self.total = 0
-            if not self.store or n == 0:
+            self.passes = 'count'
+            if n == 0:
                 return
-            # layout + pass 2: store trajectories and the rebound log
+            if not self.store:
+                # scalars only: one pass with the post-pass folded in
+                p = self._params(0)
+                _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
+                                             _ptr(init_mult), C.byref(full_out()), stream))
+                return
             n_tiles = (n + TILE - 1) // TILE
             self.tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
             total = C.c_int64(0)
+
+            # Small fans: ONE speculative storing pass into a provisional layout with the same generous room for every
+            # tile, then the exact layout and a compaction copy.  Valid when every ray fitted; otherwise (and for big
+            # fans, where the padding would cost too much memory) count -> layout -> store.
+            room = int(self.kw['n_steps_max']) + 1
+            if n_tiles * room * TILE * 16 > SPECULATIVE_BYTES:
+                room = min(room, SPECULATIVE_ROOM)
+            nrm = int(self.kw['n_rebounds_max'])
+            if n_tiles * room * TILE * 16 <= SPECULATIVE_BYTES:
+                out = full_out()
+                alloc_log(out, nrm + 1 if nrm > -1 else REBOUND_LOG_CAP_DEFAULT)
+                off0 = torch.arange(n_tiles + 1, dtype=torch.int64, device=dev) * (room * TILE)
+                X0 = torch.empty(n_tiles * room * TILE, **f64)
+                Z0 = torch.empty(n_tiles * room * TILE, **f64)
+                C0 = torch.empty(n_tiles * room * TILE, **f64) if store_c else None
+                cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
+                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), C.byref(total), stream))
+                fitted = int(total.value) <= n_tiles * room * TILE and int(self.tile_off.diff().max().item()) <= room * TILE
+                if fitted and not bool((self.status == _lib.RAY_ERR_REBOUND_LOG).any().item()):
+                    self.total = int(total.value)
+                    self.X = torch.empty(self.total, **f64)
+                    self.Z = torch.empty(self.total, **f64)
+                    self.Cpt = torch.empty(self.total, **f64) if store_c else None
+                    _lib.check(L.rt2d_traj_compact(off0.data_ptr(), self.tile_off.data_ptr(), n, X0.data_ptr(), Z0.data_ptr(),
+                                                   _ptr(C0), self.X.data_ptr(), self.Z.data_ptr(), _ptr(self.Cpt), stream))
+                    self._out = out
+                    self.passes = 'speculative'
+                    return
+                del X0, Z0, C0
+
+            # pass 1: count points and rebounds only (no post-pass, no stores)
+            cnt = _lib.Rt2dRayOut()
+            cnt.n_pts, cnt.n_rebounds = self.n_pts.data_ptr(), self.n_rebounds.data_ptr()
+            p = self._params(0)
+            _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
+                                         _ptr(init_mult), C.byref(cnt), stream))
             _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), C.byref(total), stream))
             self.total = int(total.value)
-            cap = max(1, int(self.n_rebounds.max().item()))
-            self.rebound_cap = cap
+            # pass 2: store trajectories, the rebound log and the post-pass scalars
+            out = full_out()
+            alloc_log(out, max(1, int(self.n_rebounds.max().item())))
             self.X = torch.empty(self.total, **f64)
             self.Z = torch.empty(self.total, **f64)
             self.Cpt = torch.empty(self.total, **f64) if store_c else None
-            self.reb_step = torch.full((cap, n), -1, **i32)
-            self.reb_surface = torch.zeros((cap, n), dtype=torch.uint8, device=dev)
-            self.reb_velocity = torch.zeros((cap, n), **f64)
-            self.reb_angle = torch.zeros((cap, n), **f64)
-            self.reb_pos_x = torch.zeros((cap, n), **f64)
-            self.reb_pos_z = torch.zeros((cap, n), **f64)
-            out.reb_step, out.reb_surface = self.reb_step.data_ptr(), self.reb_surface.data_ptr()
-            out.reb_velocity, out.reb_angle = self.reb_velocity.data_ptr(), self.reb_angle.data_ptr()
-            out.reb_pos_x, out.reb_pos_z = self.reb_pos_x.data_ptr(), self.reb_pos_z.data_ptr()
-            p = self._params(cap)
-            _lib.check(L.rt2d_cast_write(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
-                                         _ptr(init_mult), C.byref(out), self.tile_off.data_ptr(), self.X.data_ptr(),
-                                         self.Z.data_ptr(), _ptr(self.Cpt), stream))
+            cast_write(out, self.rebound_cap, self.tile_off, self.X, self.Z, self.Cpt)
             self._out = out
+            self.passes = 'count+store'
 
     # -- host copies ------------------------------------------------------------------------------
     def host(self, name):
