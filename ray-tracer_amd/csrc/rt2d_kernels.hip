@@ -199,10 +199,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     const bool has_target = POST && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
     TargetTrack tt;
-    if (POST || WRITE) {
-        int jz = rt2d_piece(tab, e.cz, z);
-        c_pt = rt2d_quad_at(tab, e.cz, jz, z - tab[e.cz.off_breaks + jz], 0);       // C[0] = calc_c(z0), ray.py:273
-    }
+    if (POST || WRITE) c_pt = rt2d_eval_c(tab, e.cz, z);                  // C[0] = calc_c(z0), ray.py:273
     if (POST) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
     if (WRITE && room > 0) { *px = x; *pz = z; if (pc) *pc = c_pt; }
 
@@ -220,8 +217,8 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             if (out == 1 || out == 2) { stop = out; break; }
         }
 
-        const double z_floor = rt2d_eval_lin(tab, e.floor, x_new);        // ray.py:172-173
-        const double z_ceil = rt2d_eval_lin(tab, e.ceil, x_new);
+        double z_floor, z_ceil;
+        rt2d_eval_lin2(tab, e.floor, e.ceil, x_new, z_floor, z_ceil);     // ray.py:172-173
         if (POST) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
 
         const bool hit_floor = z_new < z_floor;
@@ -270,11 +267,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                 if (WRITE && n_pts < room) {
                     px += RT2D_WAVE; pz += RT2D_WAVE;
                     *px = x_new; *pz = z_new;
-                    if (pc) {
-                        pc += RT2D_WAVE;
-                        int j = rt2d_piece(tab, e.cz, z_new);
-                        *pc = rt2d_quad_at(tab, e.cz, j, z_new - tab[e.cz.off_breaks + j], 0);
-                    }
+                    if (pc) { pc += RT2D_WAVE; *pc = rt2d_eval_c(tab, e.cz, z_new); }
                 }
                 n_pts += 1;
                 stop = RT2D_STOP_MAX_REBOUNDS;
@@ -295,10 +288,8 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             L += dL; T += dL / c_pt;                                       // ray.py:272-275
         }
         x = x_new; z = z_new;
-        int j = rt2d_piece(tab, e.cz, z);
-        double d = z - tab[e.cz.off_breaks + j];
-        c = rt2d_quad_at(tab, e.cz, j, d, 0);
-        double dz_c = rt2d_quad_at(tab, e.cz, j, d, 1);
+        double dz_c;
+        rt2d_eval_cz(tab, e.cz, z, c, dz_c);
         if (POST) {
             c_pt = c;
             min_x = fmin(min_x, x); max_x = fmax(max_x, x);
@@ -400,7 +391,7 @@ struct PostArgs {
 
 __global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    const int cz_doubles = a.env.floor.off_breaks;     // the fused c/dz_c table is the blob's first table
+    const int cz_doubles = a.env.cz_doubles;           // the fused c/dz_c table is the blob's first table
     for (int i = threadIdx.x; i < cz_doubles; i += blockDim.x) s_tab[i] = a.blob[i];
     __syncthreads();
     const double* tab = s_tab;
@@ -410,8 +401,7 @@ __global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
     const int np = a.n_pts[r];
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
     double xp = a.X[base], zp = a.Z[base];
-    int j = rt2d_piece(tab, cz, zp);
-    double cp = rt2d_quad_at(tab, cz, j, zp - tab[cz.off_breaks + j], 0);
+    double cp = rt2d_eval_c(tab, cz, zp);
     double L = 0.0, T = 0.0;
     if (a.dL) a.dL[base] = 0.0;
     if (a.L) a.L[base] = 0.0;
@@ -425,8 +415,7 @@ __global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
         double dL = sqrt(ddx * ddx + ddz * ddz);
         double dT = dL / cp;
         L += dL; T += dT;
-        j = rt2d_piece(tab, cz, z);
-        cp = rt2d_quad_at(tab, cz, j, z - tab[cz.off_breaks + j], 0);
+        cp = rt2d_eval_c(tab, cz, z);
         if (a.dL) a.dL[o] = dL;
         if (a.L) a.L[o] = L;
         if (a.C) a.C[o] = cp;
@@ -512,11 +501,12 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
         double ddx = x - xp, ddz = z - zp;
         double dL = sqrt(ddx * ddx + ddz * ddz);
         // six depth factors at the START point of the segment (ray.py:346 uses XZ[:-1, 1])
-        int j = rt2d_piece(tab, ab, zp);
-        double d = zp - tab[ab.off_breaks + j];
-        double f1 = rt2d_quad_at(tab, ab, j, d, 0), f2 = rt2d_quad_at(tab, ab, j, d, 1);
-        double A2 = rt2d_quad_at(tab, ab, j, d, 2), E1 = rt2d_quad_at(tab, ab, j, d, 3);
-        double E2 = rt2d_quad_at(tab, ab, j, d, 4), E3 = rt2d_quad_at(tab, ab, j, d, 5);
+        double rec[20];
+        rt2d_lookup<19>(tab, ab, zp, rec);
+        double d = zp - rec[0];
+        double f1 = rt2d_quad_of(rec, d, 0), f2 = rt2d_quad_of(rec, d, 1);
+        double A2 = rt2d_quad_of(rec, d, 2), E1 = rt2d_quad_of(rec, d, 3);
+        double E2 = rt2d_quad_of(rec, d, 4), E3 = rt2d_quad_of(rec, d, 5);
         double f1s = f1 * f1, f2s = f2 * f2;
         while (s >= next_reb_at) {                                          // ray.py:350-362
             int64_t kk = (int64_t)next_reb * a.n + r;
@@ -824,10 +814,10 @@ int32_t rt2d_version(void) { return 100; }
 
 static double host_eval_quad0(const std::vector<double>& blob, const DevTable& t, double x) {
     int j = 0;
-    for (int k = 0; k < t.n_pieces; ++k) if (blob[t.off_breaks + k] <= x) j = k;
-    double d = x - blob[t.off_breaks + j];
-    const double* c = &blob[t.off_coef + (size_t)j * t.stride];
-    return (c[0] * d + c[1]) * d + c[2];
+    for (int k = 0; k < t.n_pieces; ++k) if (blob[t.off + (size_t)k * t.stride] <= x) j = k;
+    const double* r = &blob[t.off + (size_t)j * t.stride];
+    double d = x - r[0];
+    return (r[1] * d + r[2]) * d + r[3];
 }
 
 static bool same_breaks(const Rt2dTable& a, const Rt2dTable& b) {
@@ -835,7 +825,8 @@ static bool same_breaks(const Rt2dTable& a, const Rt2dTable& b) {
     return memcmp(a.breaks, b.breaks, sizeof(double) * (a.n_pieces + 1)) == 0;
 }
 
-// appends `count` host tables that share their breaks as one fused device table
+// appends `count` host tables that share their breaks as one fused device table of records
+// [break_j, coefficients of table 0, of table 1, ...] plus a final record holding break_n
 static int32_t pack_table(std::vector<double>& blob, const Rt2dTable* tabs, int count, int order, int rel_to,
                           DevTable* out, const char* name) {
     const Rt2dTable& t0 = tabs[0];
@@ -846,16 +837,17 @@ static int32_t pack_table(std::vector<double>& blob, const Rt2dTable* tabs, int 
     }
     const int n = t0.n_pieces;
     for (int j = 0; j < n; ++j) if (!(t0.breaks[j + 1] > t0.breaks[j])) return fail("table %s: breaks not increasing", name);
-    if (blob.size() & 1) blob.push_back(0.0);                  // keep every table 16-byte aligned
-    out->off_breaks = (int32_t)blob.size() - rel_to;
-    blob.insert(blob.end(), t0.breaks, t0.breaks + n + 1);
-    if (blob.size() & 1) blob.push_back(0.0);
-    out->off_coef = (int32_t)blob.size() - rel_to;
-    for (int j = 0; j < n; ++j)
+    const int stride = 1 + order * count;
+    out->off = (int32_t)blob.size() - rel_to;
+    for (int j = 0; j < n; ++j) {
+        blob.push_back(t0.breaks[j]);
         for (int k = 0; k < count; ++k)
             for (int q = 0; q < order; ++q) blob.push_back(tabs[k].coef[(size_t)j * order + q]);
+    }
+    blob.push_back(t0.breaks[n]);
+    for (int q = 1; q < stride; ++q) blob.push_back(0.0);      // the last record is only read at [0]
     out->n_pieces = n;
-    out->stride = order * count;
+    out->stride = stride;
     out->oob = t0.oob;
     out->lo = t0.breaks[0];
     out->hi = t0.breaks[n];
@@ -881,6 +873,7 @@ int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
     int32_t rc = 0;
     Rt2dTable cz[2] = {d->c, d->dz_c};
     if ((rc = pack_table(blob, cz, 2, 3, 0, &e.cz, "c/dz_c"))) { delete env; return rc; }
+    e.cz_doubles = (int32_t)blob.size();
     if ((rc = pack_table(blob, &d->floor, 1, 2, 0, &e.floor, "floor"))) { delete env; return rc; }
     if ((rc = pack_table(blob, &d->ceil, 1, 2, 0, &e.ceil, "ceil"))) { delete env; return rc; }
     if ((rc = pack_table(blob, &d->dx_floor, 1, 3, 0, &e.dx_floor, "dx_floor"))) { delete env; return rc; }
@@ -1041,7 +1034,7 @@ int32_t rt2d_post(rt2d_env_t env, const double* X, const double* Z, const int64_
     PostArgs a; memset(&a, 0, sizeof a);
     a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts; a.n = n;
     a.dL = dL; a.L = L; a.C = C; a.dT = dT; a.T = T;
-    const size_t lds = (size_t)env->dev.floor.off_breaks * sizeof(double);
+    const size_t lds = (size_t)env->dev.cz_doubles * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_post: sound-speed table does not fit in LDS");
     HIP_OK(hipFuncSetAttribute((const void*)rt2d_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int block = (n <= 64 * 512) ? 64 : 256;
