@@ -23,7 +23,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, 'librt2d_oracle.so')
 _SRC = os.path.join(_HERE, 'rt2d_oracle.c')
 
-STOP_NAMES = [None, 'exit-xmin', 'exit-xmax', 'exit-zmin', 'exit-zmax', 'max-rebounds', 'backprop', 'max-iter']
+STOP_NAMES = [None, 'exit-xmin', 'exit-xmax', 'exit-zmin', 'exit-zmax', 'max-rebounds', 'backprop', 'max-iter',
+              'power-cutoff']
 
 
 def compile(force=False):
@@ -363,6 +364,36 @@ def gain(env, ray, freq):
                ray.reb_surface.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(ray.reb_velocity), _dp(ray.reb_angle),
                _dp(ray.reb_pz), ZP1, ZP2, _dp(G))
     return G
+
+
+def apply_power_cutoff(env, ray, power_cutoff, freq, target=None):
+    """Opt-in power termination (SURVEY trap 2; not in the reference).  The rule is stated on the UN-truncated ray:
+    keep points 0..j where j is the first index with 10**(G[freq][j]/10) < power_cutoff (G from populate_NEW,
+    ray.py:339-369); stop reason 'power-cutoff' -- except when j is the final point of a ray that ended on
+    max-rebounds, which stays as it is.  Rebounds after point j are dropped, the post-pass is redone, a ray that
+    failed (status -1) AFTER point j becomes a good truncated ray.  Returns (ray, j or None, dB distance of the
+    decision from the threshold: min |G - G_cut| over the examined points)."""
+    if not hasattr(ray, 'dL_full'):
+        post_ray(env, ray, target)
+    G = gain(env, ray, freq)
+    with np.errstate(over='ignore'):
+        below = np.nonzero(np.power(10., G / 10) < power_cutoff)[0]
+    g_cut = 10 * np.log10(power_cutoff)
+    if below.size == 0:
+        return ray, None, float(np.min(np.abs(G - g_cut)))
+    j = int(below[0])
+    dist = float(np.min(np.abs(G[:j + 1] - g_cut)))
+    if ray.stop_code == 5 and ray.status == 0 and j == ray.steps - 1:
+        return ray, j, dist
+    keep = ray.reb_step <= j
+    out = ray_from_points(ray.XZ[:j + 1], ray.reb_step[keep], ray.reb_surface[keep], ray.reb_velocity[keep],
+                          ray.reb_angle[keep], ray.reb_pz[keep])
+    out.reb_px = ray.reb_px[keep] if hasattr(ray, 'reb_px') else None
+    out.angle = getattr(ray, 'angle', None)
+    out.margin = getattr(ray, 'margin', np.inf)
+    out.stop_code, out.stop_reason = 8, 'power-cutoff'
+    post_ray(env, out, target)
+    return out, j, dist
 
 
 def plot_range(rays):

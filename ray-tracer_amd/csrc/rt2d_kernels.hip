@@ -58,6 +58,7 @@ struct CastArgs {
     Rt2dRayOut out;
     const int64_t* tile_off;
     double* X; double* Z; double* C;
+    double g_cut;                 // power cut-off in dB, 10*log10(power_cutoff); only read by the CUTOFF kernels
 };
 
 __device__ __forceinline__ double rt2d_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
@@ -121,6 +122,43 @@ struct TargetTrack {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------
+// physics closed forms shared by the gain kernel and the in-cast running gain (ray.py:339-369)
+static __constant__ double k_A1 = 0.106, k_A3 = 0.00049;                  // model_absorption.py:34-35
+#define RT2D_WAVE_HEIGHT_RMS 2.0                                          // preferences.py:11
+#define RT2D_DZ_SEDIMENT 2.0                                              // preferences.py:12
+#define RT2D_ZP1 2688000.0                                                // mean of 5 sediments, profile_impedance.py:17-18
+#define RT2D_ZP2 17000000.0                                               // rock, profile_impedance.py:19
+
+__device__ __forceinline__ double rt2d_refcoef_surface(double wavelength, double angle) {   // model_reflection.py:11-18
+    double v = 2 * M_PI / wavelength * RT2D_WAVE_HEIGHT_RMS * sin(angle);
+    return exp(-2 * (v * v));
+}
+
+__device__ __forceinline__ double rt2d_refcoef_sediment(double wavelength, double Zp0) {     // model_reflection.py:21-46
+    double k1 = 2 * M_PI / wavelength;
+    double r01 = (RT2D_ZP1 - Zp0) / (RT2D_ZP1 + Zp0);
+    double r12 = (RT2D_ZP2 - RT2D_ZP1) / (RT2D_ZP2 + RT2D_ZP1);
+    double th = -2 * k1 * RT2D_DZ_SEDIMENT;
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    double er = r12 * cs, ei = r12 * sn;
+    double nr = r01 + er, ni = ei;
+    double dr = 1 + r01 * er, di = r01 * ei;
+    return hypot(nr, ni) / hypot(dr, di);
+}
+
+// alpha(f, z) in dB/km from the six depth factors of one fused absorption record (model_absorption.py:37-44)
+__device__ __forceinline__ double rt2d_alpha(const double* rec, double d, double ff) {
+    double f1 = rt2d_quad_of(rec, d, 0), f2 = rt2d_quad_of(rec, d, 1);
+    double A2 = rt2d_quad_of(rec, d, 2), E1 = rt2d_quad_of(rec, d, 3);
+    double E2 = rt2d_quad_of(rec, d, 4), E3 = rt2d_quad_of(rec, d, 5);
+    double alpha_1 = k_A1 * (f1 * ff) / (f1 * f1 + ff);
+    double alpha_2 = A2 * (f2 * ff) / (f2 * f2 + ff);
+    double alpha_3 = k_A3 * ff;
+    return alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
+}
+
 // Rarely used launch data (rebound branch, final stores) is parked in LDS instead of scalar registers: the hot
 // loop alone needs ~90 SGPRs of table descriptors and bounds, and everything beyond the budget would be spilled
 // to v_writelane/v_readlane pairs inside the loop.
@@ -142,7 +180,11 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 
 // WRITE: store the trajectory.  LDS_TABLES: step section of the blob staged in LDS.  POST: also produce the scalar
 // post-pass (L, T, range, target products, decision margin); the counting pass of a stored cast does not need it.
-template <bool WRITE, bool LDS_TABLES, bool POST>
+// CUTOFF: opt-in termination on ray power (not in the reference, SURVEY trap 2): the gain of populate_NEW at
+// p.cutoff_freq is carried along (S = absorption cumsum, A = rebound losses, exactly the gain kernel's expressions)
+// and the ray ends with the first point whose G = S + A is below the cut-off; that point is kept.  The gain tables
+// are read from global memory here (they sit behind the step section of the blob).
+template <bool WRITE, bool LDS_TABLES, bool POST, bool CUTOFF>
 __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
@@ -202,6 +244,10 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     if (POST || WRITE) c_pt = rt2d_eval_c(tab, e.cz, z);                  // C[0] = calc_c(z0), ray.py:273
     if (POST) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
     if (WRITE && room > 0) { *px = x; *pz = z; if (pc) *pc = c_pt; }
+    // running gain at the cut-off frequency
+    double g_S = 0.0, g_A = 0.0, g_pend = 0.0, g_ff = 0.0;
+    const double* gtab = a.blob + e.gain_off;
+    if (CUTOFF) { double f = p.cutoff_freq / 1000; g_ff = f * f; }
 
     for (int i = 0; i < p.n_steps_max; ++i) {
         // step sizing (ray.py:153-154)
@@ -252,6 +298,12 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                 status = RT2D_RAY_ERR_REBOUND_LOG;
             }
             n_reb += 1;
+            if (CUTOFF) {                                                   // ray.py:350-362; applies from the NEXT point on
+                double wavelength = c / p.cutoff_freq;
+                double rc = hit_floor ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, e.imp, z, nullptr))
+                                      : rt2d_refcoef_surface(wavelength, ang);
+                g_pend = 10 * log10(rc);
+            }
             if (POST) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             const int nrm = cold->n_rebounds_max;
             if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended
@@ -282,10 +334,19 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         }
 
         // accept the point (ray.py:235-247)
-        if (POST) {
+        bool cut = false;
+        if (POST || CUTOFF) {
             double ddx = x_new - x, ddz = z_new - z;
             double dL = sqrt(ddx * ddx + ddz * ddz);                       // ray.py:271
-            L += dL; T += dL / c_pt;                                       // ray.py:272-275
+            if (POST) { L += dL; T += dL / c_pt; }                         // ray.py:272-275
+            if (CUTOFF) {
+                double rec[20];
+                rt2d_lookup<19>(gtab, e.absorb, z, rec);                   // factors at the START of the segment, ray.py:346
+                double dG = -1 * rt2d_alpha(rec, z - rec[0], g_ff) / 1000 * dL;
+                g_S += dG;
+                cut = (g_S + g_A) < a.g_cut;
+                g_A += g_pend; g_pend = 0.0;
+            }
         }
         x = x_new; z = z_new;
         double dz_c;
@@ -302,6 +363,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             if (pc) { pc += RT2D_WAVE; *pc = c; }
         }
         n_pts += 1;
+        if (CUTOFF && cut) { stop = RT2D_STOP_POWER_CUTOFF; break; }
         x_dir = rt2d_sign(kx);
         dx_z = kz / kx;
         double dxdx_z = mult * dz_c / (c * c * c);
@@ -427,30 +489,6 @@ __global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
 
 // ------------------------------------------------------------------------------------------------------
 // gain (ray.py:339-369)
-static __constant__ double k_A1 = 0.106, k_A3 = 0.00049;                  // model_absorption.py:34-35
-#define RT2D_WAVE_HEIGHT_RMS 2.0                                          // preferences.py:11
-#define RT2D_DZ_SEDIMENT 2.0                                              // preferences.py:12
-#define RT2D_ZP1 2688000.0                                                // mean of 5 sediments, profile_impedance.py:17-18
-#define RT2D_ZP2 17000000.0                                               // rock, profile_impedance.py:19
-
-__device__ __forceinline__ double rt2d_refcoef_surface(double wavelength, double angle) {   // model_reflection.py:11-18
-    double v = 2 * M_PI / wavelength * RT2D_WAVE_HEIGHT_RMS * sin(angle);
-    return exp(-2 * (v * v));
-}
-
-__device__ __forceinline__ double rt2d_refcoef_sediment(double wavelength, double Zp0) {     // model_reflection.py:21-46
-    double k1 = 2 * M_PI / wavelength;
-    double r01 = (RT2D_ZP1 - Zp0) / (RT2D_ZP1 + Zp0);
-    double r12 = (RT2D_ZP2 - RT2D_ZP1) / (RT2D_ZP2 + RT2D_ZP1);
-    double th = -2 * k1 * RT2D_DZ_SEDIMENT;
-    double sn, cs;
-    sincos(th, &sn, &cs);
-    double er = r12 * cs, ei = r12 * sn;
-    double nr = r01 + er, ni = ei;
-    double dr = 1 + r01 * er, di = r01 * ei;
-    return hypot(nr, ni) / hypot(dr, di);
-}
-
 struct GainArgs {
     DevEnv env; const double* blob;
     const double* X; const double* Z; const int64_t* tile_off; const int32_t* n_pts;
@@ -916,7 +954,7 @@ static bool wants_post(const Rt2dRayOut& o) {
     return o.range || o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin;
 }
 
-template <bool WRITE, bool POST>
+template <bool WRITE, bool POST, bool CUTOFF>
 static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
     const int64_t n = a.n;
     const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
@@ -931,11 +969,11 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a, hipStream_t strea
     const int64_t grid = (n + block - 1) / block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     if (in_lds) {
-        auto k = rt2d_cast_kernel<WRITE, true, POST>;
+        auto k = rt2d_cast_kernel<WRITE, true, POST, CUTOFF>;
         HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST>), dim3((unsigned)grid), dim3(block), lds, stream, a);
+        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST, CUTOFF>), dim3((unsigned)grid), dim3(block), lds, stream, a);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -943,7 +981,8 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a, hipStream_t strea
 
 template <bool WRITE>
 static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
-    return wants_post(a.out) ? launch_cast2<WRITE, true>(env, a, stream) : launch_cast2<WRITE, false>(env, a, stream);
+    if (a.p.power_cutoff > 0) return launch_cast2<WRITE, true, true>(env, a, stream);
+    return wants_post(a.out) ? launch_cast2<WRITE, true, false>(env, a, stream) : launch_cast2<WRITE, false, false>(env, a, stream);
 }
 }  // extern "C++"
 
@@ -957,7 +996,8 @@ static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const
     if (!(p->dx_max > 0) || !(p->dz_max > 0)) return fail("rt2d_cast: dx_max and dz_max must be positive");
     if (p->n_steps_max < 0) return fail("rt2d_cast: negative n_steps_max");
     if (p->rebound_cap < 0) return fail("rt2d_cast: negative rebound_cap");
-    if (p->power_cutoff > 0) return fail("rt2d_cast: power_cutoff is not implemented in this build");
+    if (p->power_cutoff != p->power_cutoff) return fail("rt2d_cast: power_cutoff is NaN");
+    if (p->power_cutoff > 0 && !(p->cutoff_freq > 0)) return fail("rt2d_cast: power_cutoff needs cutoff_freq > 0");
     return 0;
 }
 
@@ -967,6 +1007,7 @@ static CastArgs make_cast_args(rt2d_env_t env, const double* angles, int64_t n, 
     memset(&a, 0, sizeof a);
     a.env = env->dev; a.blob = env->blob; a.angles = angles; a.init_slope = init_slope; a.init_mult = init_mult;
     a.n = n; a.src_x = src[0]; a.src_z = src[1]; a.p = *p; a.out = *out;
+    a.g_cut = p->power_cutoff > 0 ? 10 * log10(p->power_cutoff) : -INFINITY;
     return a;
 }
 

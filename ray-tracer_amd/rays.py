@@ -39,8 +39,11 @@ def _ptr(t):
 class RayFan:
     """n rays cast together.  Device tensors; host copies of the per-ray scalars are made on demand."""
 
+    # power_cutoff / cutoff_freq: opt-in termination on ray power (NOT in the reference, whose propagate never looks at
+    # the gain): 0 = off; > 0 ends a ray with the first point whose 10**(G[cutoff_freq]/10) is below it ('power-cutoff')
     PROPAGATE_DEFAULTS = dict(backprop=True, dx_max=DX_MAX_DEFAULT, dz_max=DZ_MAX_DEFAULT,
-                              n_steps_max=N_STEPS_MAX, n_rebounds_max=N_REBOUNDS_MAX)
+                              n_steps_max=N_STEPS_MAX, n_rebounds_max=N_REBOUNDS_MAX,
+                              power_cutoff=0., cutoff_freq=1.)
 
     def __init__(self, env, source, angles, target=None, store=True, device=None, init=None, store_c=False, **kwargs):
         torch = _torch()
@@ -73,6 +76,7 @@ class RayFan:
         if self.target is not None:
             p.target[:] = [float(self.target[0]), float(self.target[1])]
         p.rebound_cap = int(rebound_cap)
+        p.power_cutoff, p.cutoff_freq = float(self.kw['power_cutoff']), float(self.kw['cutoff_freq'])
         return p
 
     def _cast(self, init, store_c):
