@@ -580,6 +580,118 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     }
 }
 
+// Small fans: with one lane per ray the loop above is a serial chain of n_pts table evaluations on a handful of
+// waves.  Two phases instead, same expressions and same summation order (so the results are bit-identical):
+//   (1) rt2d_gain_dg_kernel    dG of EVERY segment, one lane per point, all CUs busy; written into G
+//   (2) rt2d_gain_scan_kernel  per (ray, frequency) the running sum over G in place + rebound losses: the serial chain
+//                              is one add per point, the loads are issued eight points ahead.
+template <int FCH>
+__global__ void __launch_bounds__(256) rt2d_gain_dg_kernel(const GainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
+    __syncthreads();
+    const double* tab = s_tab;
+    const int64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = tile * RT2D_WAVE + lane;
+    const int np = (r < a.n) ? a.n_pts[r] : 0;
+    const int64_t t0 = a.tile_off[tile], len = a.tile_off[tile + 1] - t0;
+    const int f0 = blockIdx.z * FCH;
+    const int nf = min(FCH, a.n_freqs - f0);
+    double ff[FCH];
+#pragma unroll
+    for (int k = 0; k < FCH; ++k) { double f = ((k < nf) ? a.freqs[f0 + k] : 1.0) / 1000; ff[k] = f * f; }
+    const DevTable& ab = a.env.absorb;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.y * blockDim.x) {
+        const int s = (int)(i >> 6);
+        if (s >= np) continue;
+        const int64_t o = t0 + i;
+        if (s == 0) {
+#pragma unroll
+            for (int k = 0; k < FCH; ++k) if (k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = 0.0;
+            continue;
+        }
+        double x = a.X[o], z = a.Z[o], xp = a.X[o - RT2D_WAVE], zp = a.Z[o - RT2D_WAVE];
+        double ddx = x - xp, ddz = z - zp;
+        double dL = sqrt(ddx * ddx + ddz * ddz);
+        double rec[20];
+        rt2d_lookup<19>(tab, ab, zp, rec);
+        double d = zp - rec[0];
+        double f1 = rt2d_quad_of(rec, d, 0), f2 = rt2d_quad_of(rec, d, 1);
+        double A2 = rt2d_quad_of(rec, d, 2), E1 = rt2d_quad_of(rec, d, 3);
+        double E2 = rt2d_quad_of(rec, d, 4), E3 = rt2d_quad_of(rec, d, 5);
+        double f1s = f1 * f1, f2s = f2 * f2;
+#pragma unroll
+        for (int k = 0; k < FCH; ++k) {
+            double alpha_1 = k_A1 * (f1 * ff[k]) / (f1s + ff[k]);          // model_absorption.py:37-44
+            double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
+            double alpha_3 = k_A3 * ff[k];
+            double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
+            double dG = -1 * alpha / 1000 * dL;                            // ray.py:346
+            if (k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = dG;
+        }
+    }
+}
+
+#define GAIN_SCAN_AHEAD 16
+__global__ void __launch_bounds__(64) rt2d_gain_scan_kernel(const GainArgs a) {
+    // per lane: cumulative rebound loss after rebound k and the first point that carries it, kept in LDS so that the
+    // scan loop below issues no memory instruction other than its own loads and stores of G
+    extern __shared__ __attribute__((aligned(16))) double s_loss[];        // [cap][64] doubles, then [cap][64] ints
+    int* s_at = reinterpret_cast<int*>(s_loss + (size_t)a.rebound_cap * RT2D_WAVE);
+    const int lane = threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const int fi = blockIdx.y;
+    const double fr = a.freqs[fi];
+    const double* gtab = a.blob + a.env.gain_off;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+    double* G = a.G + (int64_t)fi * a.total;
+    const int nreb = min(a.n_rebounds[r], a.rebound_cap);
+    {
+        double A = 0.0;
+        for (int k = 0; k < nreb; ++k) {                                        // ray.py:350-362
+            int64_t kk = (int64_t)k * a.n + r;
+            double wavelength = a.reb_velocity[kk] / fr;
+            double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
+                ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, a.env.imp, a.reb_pos_z[kk], nullptr))
+                : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
+            A += 10 * log10(rc);
+            s_loss[k * RT2D_WAVE + lane] = A;
+            s_at[k * RT2D_WAVE + lane] = a.reb_step[kk] + 1;
+        }
+    }
+    int next_reb = 0;
+    int next_reb_at = (nreb > 0) ? s_at[lane] : 0x7fffffff;
+    double S = 0.0, A = 0.0;
+    // two register buffers: the loads of the next GAIN_SCAN_AHEAD points are in flight while this batch is summed
+    double cur[GAIN_SCAN_AHEAD], nxt[GAIN_SCAN_AHEAD];
+    const int last = max(np - 1, 0);
+#pragma unroll
+    for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) cur[u] = G[base + (int64_t)min(1 + u, last) * RT2D_WAVE];
+    for (int s0 = 1; s0 < np; s0 += GAIN_SCAN_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) nxt[u] = G[base + (int64_t)min(s0 + GAIN_SCAN_AHEAD + u, last) * RT2D_WAVE];
+#pragma unroll
+        for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) {
+            const int s = s0 + u;
+            while (s < np && s >= next_reb_at) {                                // a loss that starts past the end never applies
+                A = s_loss[next_reb * RT2D_WAVE + lane];
+                ++next_reb;
+                next_reb_at = (next_reb < nreb) ? s_at[next_reb * RT2D_WAVE + lane] : 0x7fffffff;
+            }
+            if (s < np) {
+                S += cur[u];                                                    // ray.py:347
+                G[base + (int64_t)s * RT2D_WAVE] = S + A;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) cur[u] = nxt[u];
+    }
+    if (a.G_end) a.G_end[(int64_t)fi * a.n + r] = S + A;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // distance to target from stored trajectories (ray.py:282-287)
 __global__ void __launch_bounds__(256) rt2d_dist_kernel(const double* X, const double* Z, const int64_t* tile_off,
@@ -609,14 +721,46 @@ __device__ __forceinline__ int64_t rt2d_floordiv(int64_t a, int64_t b) {
     return q;
 }
 
-// flat cell index of a point, or -1 when it falls outside the map (simulation.py:123-125, functions.py:16)
-__device__ __forceinline__ int64_t rt2d_cell(double x, double z, int res_x, int res_z, int64_t nz, int64_t size) {
-    int64_t ix = rt2d_floordiv((int64_t)x, res_x);
-    int64_t iz = rt2d_floordiv((int64_t)z, -1 * (int64_t)res_z);
+// Cell indices of a point: ix = int(x) // res_x, iz = int(z) // (-res_z) (simulation.py:123-125: C truncation, then
+// Python floor division).  64-bit integer division costs ~150 instructions on this hardware and there are two per
+// point, so coordinates below 2^31 take a reciprocal multiply with an exact remainder fix-up instead: t and b are
+// integers, fma(-q, b, t) is exact, and q = floor(t * (1/b)) can only be one off when t/b is an integer.
+struct HeatGeom { int32_t res_x, res_z; double rx, rz, inv_rx, inv_rz, lim; };     // lim: |coordinate| bound of the fast division
+
+__device__ __forceinline__ int64_t rt2d_fdiv_pos(double t, double b, double inv_b) {     // floor(t / b), b > 0
+    double q = floor(t * inv_b);
+    double rem = fma(-q, b, t);
+    if (rem < 0.0) q -= 1.0; else if (rem >= b) q += 1.0;
+    return (int64_t)(int32_t)q;
+}
+
+__device__ __forceinline__ void rt2d_cell_xz(const HeatGeom& g, double x, double z, int64_t& ix, int64_t& iz) {
+    if (fabs(x) < g.lim && fabs(z) < g.lim) {
+        ix = rt2d_fdiv_pos(trunc(x), g.rx, g.inv_rx);
+        iz = rt2d_fdiv_pos(-trunc(z), g.rz, g.inv_rz);          // a // (-b) == (-a) // b
+    } else {
+        ix = rt2d_floordiv((int64_t)x, g.res_x);
+        iz = rt2d_floordiv((int64_t)z, -1 * (int64_t)g.res_z);
+    }
+}
+
+// flat cell index of a point, or -1 when it falls outside the map (functions.py:16; one negative wrap as NumPy does)
+__device__ __forceinline__ int64_t rt2d_cell(const HeatGeom& g, double x, double z, int64_t nz, int64_t size) {
+    int64_t ix, iz;
+    rt2d_cell_xz(g, x, z, ix, iz);
     int64_t flat = ix * nz + iz;
     if (flat < 0) flat += size;
     if (flat < 0 || flat >= size) return -1;
     return flat;
+}
+
+// vals = (10**(G/10))**-0.1 (ray.py:317, simulation.py:129).  While 10**(G/10) is a normal double this is 10**(-G/100)
+// to ~1e-15 relative (the heat-map tolerance is 1e-12) and one exp2 replaces two pows; outside that range the two
+// pows are evaluated as written so that underflow to 0 -> inf behaves as in the reference.
+__device__ __forceinline__ double rt2d_heat_val(double g) {
+    if (g > -3000.0 && g < 3000.0) return exp2(g * -0.033219280948873623);     // -log2(10)/100
+    double tmult = pow(10.0, g / 10);
+    return pow(tmult, -0.1);
 }
 
 __device__ __forceinline__ uint32_t rt2d_hash32(uint32_t k) { k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k; }
@@ -625,7 +769,7 @@ struct HeatArgs {
     const double* X; const double* Z; const double* G; const int64_t* tile_off; const int32_t* n_pts; int64_t n;
     const uint8_t* ray_mask;                        // n bytes, nonzero = bin this ray (NULL = all)
     int32_t* work;                                  // [0] = number of rays left to the general kernel, [2 + k] = their ids
-    int32_t res_x, res_z; int64_t nx, nz;
+    HeatGeom geo; int64_t nx, nz;
     double* H; int64_t* n_dropped; int32_t cap;     // cap: hash slots per ray, power of two
 };
 
@@ -664,8 +808,8 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
             if (s0 + u < np) {
-                int64_t ix = rt2d_floordiv((int64_t)xs[u], a.res_x);
-                int64_t iz = rt2d_floordiv((int64_t)zs[u], -1 * (int64_t)a.res_z);
+                int64_t ix, iz;
+                rt2d_cell_xz(a.geo, xs[u], zs[u], ix, iz);
                 ok = ok && ix >= prev_ix && ix >= 0 && ix < a.nx && iz >= 0 && iz < a.nz;
                 prev_ix = ix;
             }
@@ -702,8 +846,8 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             int64_t cell = -1 - lane;                       // unique per lane: never merges
             double val = 0.0;
             if (s >= 0 && s < np) {
-                int64_t ix = rt2d_floordiv((int64_t)xs[u], a.res_x);
-                int64_t iz = rt2d_floordiv((int64_t)zs[u], -1 * (int64_t)a.res_z);
+                int64_t ix, iz;
+                rt2d_cell_xz(a.geo, xs[u], zs[u], ix, iz);
                 if (ix != cur_ix) {
                     cur_ix = ix;
 #pragma unroll
@@ -714,8 +858,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
 #pragma unroll
                 for (int w = 0; w < MW; ++w) if (w == word) { fresh = (seen[w] & bit) == 0; seen[w] |= bit; }
                 if (fresh) {
-                    double tmult = pow(10.0, gs[u] / 10);                      // ray.py:317
-                    val = pow(tmult, -0.1);                                    // simulation.py:129
+                    val = rt2d_heat_val(gs[u]);                                // ray.py:317, simulation.py:129
                     cell = ix * a.nz + iz;
                 }
             }
@@ -757,9 +900,9 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
     int n_cand = 0, n_drop = 0;
     for (int s = lane; s < np; s += RT2D_WAVE) {
         int64_t o = base + (int64_t)s * RT2D_WAVE;
-        int64_t cell = rt2d_cell(a.X[o], a.Z[o], a.res_x, a.res_z, a.nz, size);
+        int64_t cell = rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
         int64_t nxt = -2;
-        if (s + 1 < np) nxt = rt2d_cell(a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.res_x, a.res_z, a.nz, size);
+        if (s + 1 < np) nxt = rt2d_cell(a.geo, a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.nz, size);
         if (cell < 0) ++n_drop; else if (nxt != cell) ++n_cand;
     }
     for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_xor(n_cand, off); n_drop += __shfl_xor(n_drop, off); }
@@ -772,9 +915,9 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
         // pass A: cell -> max step
         for (int s = lane; s < np; s += RT2D_WAVE) {
             int64_t o = base + (int64_t)s * RT2D_WAVE;
-            int64_t cell = rt2d_cell(a.X[o], a.Z[o], a.res_x, a.res_z, a.nz, size);
+            int64_t cell = rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
             if (cell < 0) continue;
-            if (s + 1 < np && rt2d_cell(a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.res_x, a.res_z, a.nz, size) == cell) continue;
+            if (s + 1 < np && rt2d_cell(a.geo, a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.nz, size) == cell) continue;
             uint32_t h = rt2d_hash32((uint32_t)cell);
             if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
             unsigned long long packed = ((unsigned long long)(uint32_t)cell << 32) | (uint32_t)s;
@@ -790,9 +933,9 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
         // pass B: the step that owns its cell deposits (simulation.py:129-131)
         for (int s = lane; s < np; s += RT2D_WAVE) {
             int64_t o = base + (int64_t)s * RT2D_WAVE;
-            int64_t cell = rt2d_cell(a.X[o], a.Z[o], a.res_x, a.res_z, a.nz, size);
+            int64_t cell = rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
             if (cell < 0) continue;
-            if (s + 1 < np && rt2d_cell(a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.res_x, a.res_z, a.nz, size) == cell) continue;
+            if (s + 1 < np && rt2d_cell(a.geo, a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.nz, size) == cell) continue;
             uint32_t h = rt2d_hash32((uint32_t)cell);
             if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
             uint32_t slot = h & mask;
@@ -801,9 +944,7 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
                 if (cur == HM_EMPTY) break;
                 if ((cur >> 32) == (unsigned long long)(uint32_t)cell) {
                     if ((uint32_t)cur == (uint32_t)s) {
-                        double tmult = pow(10.0, a.G[o] / 10);                 // ray.py:317
-                        double val = pow(tmult, -0.1);                         // simulation.py:129
-                        atomicAdd(&a.H[cell], val);
+                        atomicAdd(&a.H[cell], rt2d_heat_val(a.G[o]));          // ray.py:317, simulation.py:129
                     }
                     break;
                 }
@@ -1099,8 +1240,23 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     a.rebound_cap = rebound_cap; a.n = n; a.freqs = freqs; a.n_freqs = n_freqs; a.total = total; a.G = G; a.G_end = G_end;
     const size_t lds = (size_t)env->dev.gain_doubles * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain: absorption tables do not fit in LDS");
-    const int block = (n <= 64 * 512) ? 64 : 256;
     const int fch = n_freqs >= 8 ? 8 : (n_freqs >= 3 ? 4 : n_freqs);      // frequencies per lane: amortises the 6 table evals
+    const char* tp = getenv("RT2D_GAIN_TWO_PHASE_MAX_RAYS");              // tests force either path with this
+    const size_t scan_lds = (size_t)(rebound_cap > 0 ? rebound_cap : 1) * RT2D_WAVE * 12;
+    if (G && n <= (tp ? atoll(tp) : 64 * 512) && scan_lds <= 64 * 1024) {
+        // small fan: per-point dG on the whole chip, then the running sums (see rt2d_gain_dg_kernel)
+        const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+        const unsigned split = (unsigned)(n_tiles >= 512 ? 4 : (2048 + n_tiles - 1) / n_tiles);
+        dim3 grid1((unsigned)n_tiles, split, (unsigned)((n_freqs + fch - 1) / fch));
+        void (*k1)(const GainArgs) = fch == 8 ? rt2d_gain_dg_kernel<8> : fch == 4 ? rt2d_gain_dg_kernel<4>
+                                    : fch == 2 ? rt2d_gain_dg_kernel<2> : rt2d_gain_dg_kernel<1>;
+        HIP_OK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k1, grid1, dim3(256), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(rt2d_gain_scan_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs), dim3(64), scan_lds, (hipStream_t)stream, a);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    const int block = (n <= 64 * 512) ? 64 : 256;
     dim3 grid((unsigned)((n + block - 1) / block), (unsigned)((n_freqs + fch - 1) / fch));
     void (*kern)(const GainArgs) = fch == 8 ? rt2d_gain_kernel<8> : fch == 4 ? rt2d_gain_kernel<4>
                                   : fch == 2 ? rt2d_gain_kernel<2> : rt2d_gain_kernel<1>;
@@ -1134,7 +1290,10 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     HeatArgs a; memset(&a, 0, sizeof a);
     a.X = X; a.Z = Z; a.G = G; a.tile_off = tile_off; a.n_pts = n_pts; a.n = n;
     a.ray_mask = ray_mask;
-    a.res_x = res[0]; a.res_z = res[1]; a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
+    a.geo.res_x = res[0]; a.geo.res_z = res[1]; a.geo.rx = res[0]; a.geo.rz = res[1];
+    a.geo.inv_rx = 1.0 / res[0]; a.geo.inv_rz = 1.0 / res[1];
+    a.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
+    a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
     a.cap = 4096;
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
     // below ~16k rays the latter finishes first

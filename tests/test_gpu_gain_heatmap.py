@@ -235,3 +235,20 @@ def test_heatmap_backward_and_out_of_map_rays(rt, orc):
         nd += L.orc_heatmap_add(orc._dp(Xc), orc._dp(Zc), orc._dp(G), r.steps, orc._ip(res_c), orc._ip(shape_c), orc._dp(Hs))
     assert int(dr.item()) == nd and nd > 0
     assert np.abs(Hd.cpu().numpy() - Hs).max() <= 1e-12 * Hs.max()
+
+
+def test_gain_two_phase_equals_one_pass(rt, monkeypatch):
+    """Small fans take the two-phase gain (per-point dG, then running sums), large ones the one-pass kernel: same
+    expressions in the same order, so the arrays must be identical bit for bit."""
+    g = common.load('c2_fan999')
+    freqs = [1., 1000., 20000.]
+    fan, env = _cast(rt, g)
+    fan.populate(*freqs)
+    monkeypatch.setenv('RT2D_GAIN_TWO_PHASE_MAX_RAYS', '0')
+    fan1, _ = _cast(rt, g)
+    fan1.populate(*freqs)
+    for f in freqs:
+        assert np.array_equal(fan.G_end[f].cpu().numpy(), fan1.G_end[f].cpu().numpy(), equal_nan=True)
+        for i in range(0, fan.n, 37):
+            a, b = fan.ray_slice(fan.G[f], i).cpu().numpy(), fan1.ray_slice(fan1.G[f], i).cpu().numpy()
+            assert np.array_equal(a, b, equal_nan=True)
