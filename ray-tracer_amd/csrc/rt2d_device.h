@@ -80,7 +80,9 @@ __device__ __forceinline__ void rt2d_lookup(TabPtr tab, const DevTable& t, doubl
 #pragma unroll
         for (int k = 0; k <= STRIDE; ++k) r[k] = p[k];
     }
-    const bool ok = (x >= r[0] || j == 0) && (x < r[STRIDE] || j == t.n_pieces - 1);
+    // bitwise on purpose: with && / || the compiler sinks the loads of r[1..] behind a branch on r[0], a second LDS
+    // round trip on the critical path
+    const bool ok = ((x >= r[0]) | (j == 0)) & ((x < r[STRIDE]) | (j == t.n_pieces - 1));
     if (!ok || !t.uniform) {
         j = rt2d_fix_piece(tab, t, x, j);
         auto p = tab + t.off + j * STRIDE;
@@ -121,8 +123,8 @@ __device__ __forceinline__ void rt2d_eval_lin2(TabPtr tab, const DevTable& ta, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ra[k] = pa[k]; rb[k] = pb[k]; }
     }
-    const bool oka = (xa >= ra[0] || ja == 0) && (xa < ra[3] || ja == ta.n_pieces - 1) && ta.uniform;
-    const bool okb = (xb >= rb[0] || jb == 0) && (xb < rb[3] || jb == tb.n_pieces - 1) && tb.uniform;
+    const bool oka = ((xa >= ra[0]) | (ja == 0)) & ((xa < ra[3]) | (ja == ta.n_pieces - 1)) & (ta.uniform != 0);
+    const bool okb = ((xb >= rb[0]) | (jb == 0)) & ((xb < rb[3]) | (jb == tb.n_pieces - 1)) & (tb.uniform != 0);
     if (!(oka && okb)) {
         ja = rt2d_fix_piece(tab, ta, xa, ja);
         jb = rt2d_fix_piece(tab, tb, xb, jb);

@@ -41,6 +41,7 @@ struct rt2d_env_s {
     DevEnv dev;
     double* blob;       // device
     int device;
+    int n_cu;           // compute units of that device
     std::vector<double> host_blob;
 };
 
@@ -59,6 +60,7 @@ struct CastArgs {
     const int64_t* tile_off;
     double* X; double* Z; double* C;
     double g_cut;                 // power cut-off in dB, 10*log10(power_cutoff); only read by the CUTOFF kernels
+    int32_t lanes;                // rays per wave (1..64, power of two): small fans are spread over more waves
 };
 
 __device__ __forceinline__ double rt2d_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
@@ -202,7 +204,12 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         tab = a.blob;
     }
     __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Ray of this lane.  A wave executes the rebound branch whenever ANY of its lanes rebounds, which with 64 rays is
+    // most steps; a small fan therefore uses only `lanes` lanes of each wave and spreads over up to one wave per SIMD
+    // of the chip (launch_cast2), so that a wave pays for its own few rebounds only.
+    const int lane = threadIdx.x & (RT2D_WAVE - 1);
+    if (lane >= a.lanes) return;
+    const int64_t r = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * a.lanes + lane;
     if (r >= a.n) return;
     const DevEnv& e = a.env;
     const Rt2dParams& p = a.p;
@@ -1067,6 +1074,7 @@ int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
     e.total_doubles = (int32_t)blob.size();
     e.c_surface = host_eval_quad0(blob, e.cz, 0.0);
     if (hipGetDevice(&env->device) != hipSuccess) { delete env; return fail("no HIP device available"); }
+    if (hipDeviceGetAttribute(&env->n_cu, hipDeviceAttributeMultiprocessorCount, env->device) != hipSuccess || env->n_cu <= 0) env->n_cu = 256;
     if (hipMalloc(&env->blob, blob.size() * sizeof(double)) != hipSuccess) { delete env; return fail("hipMalloc of the table blob failed"); }
     if (hipMemcpy(env->blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(env->blob); delete env; return fail("hipMemcpy of the table blob failed");
@@ -1096,18 +1104,36 @@ static bool wants_post(const Rt2dRayOut& o) {
 }
 
 template <bool WRITE, bool POST, bool CUTOFF>
-static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
+static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t stream) {
+    CastArgs a = a_in;
     const int64_t n = a.n;
     const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
     const size_t tab_bytes = (size_t)env->dev.step_doubles * sizeof(double);
     const bool in_lds = cold + tab_bytes <= RT2D_LDS_BUDGET;
     const size_t lds = cold + (in_lds ? tab_bytes : 0);
-    int block;
-    if (n <= 64 * 512) block = 64;                  // small fans: one wave per workgroup, spread over all CUs
-    else if (!in_lds || lds <= 36 * 1024) block = 256;
-    else if (lds <= 76 * 1024) block = 512;
-    else block = 1024;                              // one LDS copy of the tables per CU, 16 waves share it
-    const int64_t grid = (n + block - 1) / block;
+    // Launch shape.  Measured on MI355X (tools/microbench_lanes.py): a wave steps fastest when it is alone on its CU
+    // (co-resident waves cost each other 0.4-0.7 us per step even on different SIMDs) and when few of its lanes are in
+    // use (a wave runs the rebound branch whenever ANY lane rebounds).  So: up to one wave per CU with as few rays per
+    // wave as that allows; beyond 64 rays per wave, as many waves per workgroup as keeps every CU busy, at most 16
+    // (1024 threads share one LDS copy of the tables).
+    static const int64_t n_cu_env = getenv("RT2D_CAST_CUS") ? atoll(getenv("RT2D_CAST_CUS")) : 0;
+    const int64_t n_cu = n_cu_env > 0 ? n_cu_env : env->n_cu;
+    int block = RT2D_WAVE;
+    a.lanes = RT2D_WAVE;
+    if (n <= n_cu * RT2D_WAVE) {
+        int lanes = 1;
+        while ((int64_t)lanes * n_cu < n) lanes *= 2;
+        a.lanes = lanes;
+    } else {
+        // smallest workgroup with which all workgroups are resident at once (LDS decides how many fit on a CU)
+        const int64_t waves = (n + RT2D_WAVE - 1) / RT2D_WAVE;
+        const int64_t per_cu = lds > 0 ? (int64_t)((160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1) : 16;
+        int wpb = 1;
+        while (wpb < 16 && (waves + wpb - 1) / wpb > n_cu * per_cu) wpb *= 2;
+        block = wpb * RT2D_WAVE;
+    }
+    const int64_t rays_per_block = (int64_t)(block / RT2D_WAVE) * a.lanes;
+    const int64_t grid = (n + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     if (in_lds) {
         auto k = rt2d_cast_kernel<WRITE, true, POST, CUTOFF>;

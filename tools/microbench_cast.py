@@ -47,7 +47,7 @@ def run(n, lean, n_steps_max=100000, reps=10):
     return ms, steps
 
 
-for n in (999, 16384, 65536, 262144, 1 << 20):
+for n in ((999,) if os.environ.get('RT2D_MB_SHORT') else (999, 16384, 65536, 262144, 1 << 20)):
     for lean in (False, True):
         ms, steps = run(n, lean, reps=10 if n < 100000 else 3)
         print(f'n={n:8d} lean={lean!s:5} {ms:8.3f} ms  {steps / ms / 1e6:8.2f} G steps/s  max-steps/ray={steps / n:.0f}', flush=True)
