@@ -180,13 +180,14 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
     return out;
 }
 
-// WRITE: store the trajectory.  LDS_TABLES: step section of the blob staged in LDS.  POST: also produce the scalar
-// post-pass (L, T, range, target products, decision margin); the counting pass of a stored cast does not need it.
+// WRITE: store the trajectory.  LDS_TABLES: step section of the blob staged in LDS.
+// POST: 0 = counts only (the counting pass of a stored cast); 1 = + bounding box of the ray (what the heat-map
+// pipeline needs); 2 = the whole scalar post-pass (L, T, target products; the decision margin when out.margin is set).
 // CUTOFF: opt-in termination on ray power (not in the reference, SURVEY trap 2): the gain of populate_NEW at
 // p.cutoff_freq is carried along (S = absorption cumsum, A = rebound losses, exactly the gain kernel's expressions)
 // and the ray ends with the first point whose G = S + A is below the cut-off; that point is kept.  The gain tables
 // are read from global memory here (they sit behind the step section of the blob).
-template <bool WRITE, bool LDS_TABLES, bool POST, bool CUTOFF>
+template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF>
 __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
@@ -205,8 +206,8 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     }
     __syncthreads();
     // Ray of this lane.  A wave executes the rebound branch whenever ANY of its lanes rebounds, which with 64 rays is
-    // most steps; a small fan therefore uses only `lanes` lanes of each wave and spreads over up to one wave per SIMD
-    // of the chip (launch_cast2), so that a wave pays for its own few rebounds only.
+    // most steps; a small fan therefore uses only `lanes` lanes of each wave and spreads over up to one wave per CU
+    // (launch_cast2), so that a wave pays for its own few rebounds only.
     const int lane = threadIdx.x & (RT2D_WAVE - 1);
     if (lane >= a.lanes) return;
     const int64_t r = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * a.lanes + lane;
@@ -242,14 +243,16 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     double x_dir = 1.0, kx = x_dir, kz = dx_z;
 
     // post-pass state (ray.py:263-279)
+    constexpr bool FULL = POST >= 2;
     double c_pt = 0.0, L = 0.0, T = 0.0;
     double min_x = x, max_x = x, min_z = z, max_z = z;
     double margin = INFINITY;
-    const bool has_target = POST && p.has_target != 0;
+    const bool want_margin = FULL && a.out.margin != nullptr;
+    const bool has_target = FULL && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
     TargetTrack tt;
-    if (POST || WRITE) c_pt = rt2d_eval_c(tab, e.cz, z);                  // C[0] = calc_c(z0), ray.py:273
-    if (POST) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
+    if (FULL || (WRITE && pc)) c_pt = rt2d_eval_c(tab, e.cz, z);          // C[0] = calc_c(z0), ray.py:273
+    if (FULL) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
     if (WRITE && room > 0) { *px = x; *pz = z; if (pc) *pc = c_pt; }
     // running gain at the cut-off frequency
     double g_S = 0.0, g_A = 0.0, g_pend = 0.0, g_ff = 0.0;
@@ -261,7 +264,25 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         if (fabs(dx_z) > dx_z_max) { double s = p.dz_max / fabs(dx_z); kx *= s; kz *= s; }
         else { kx *= p.dx_max; kz *= p.dx_max; }
         double x_new = x + kx, z_new = z + kz;                            // ray.py:157
-        if (POST) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+
+        // The three table records the common step needs -- floor and ceiling under x_new (ray.py:172-173; both tables
+        // clamp, checked by rt2d_env_create) and c, dc/dz at z_new (ray.py:237-238) -- are fetched in ONE batch of
+        // independent LDS reads from guessed pieces.  The guesses are verified below; the sound-speed record is only
+        // used if the point is accepted as it stands (a rebound moves it, and then the lookup is redone).
+        const double xa = fmin(fmax(x_new, e.floor.lo), e.floor.hi), xb = fmin(fmax(x_new, e.ceil.lo), e.ceil.hi);
+        int ja = rt2d_guess(e.floor, xa), jb = rt2d_guess(e.ceil, xb);
+        const int jz = rt2d_guess(e.cz, z_new);
+        double ra[4], rb[4], rz[8];
+        {
+            auto pa = tab + e.floor.off + ja * 3;
+            auto pb = tab + e.ceil.off + jb * 3;
+            auto pzr = tab + e.cz.off + jz * 7;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ra[k] = pa[k]; rb[k] = pb[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rz[k] = pzr[k];
+        }
+        if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
 
         // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
         // clipped in x is still inside in z; the clipped point is NOT appended
@@ -270,13 +291,26 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             if (out == 1 || out == 2) { stop = out; break; }
         }
 
-        double z_floor, z_ceil;
-        rt2d_eval_lin2(tab, e.floor, e.ceil, x_new, z_floor, z_ceil);     // ray.py:172-173
-        if (POST) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
+        {
+            const bool oka = ((xa >= ra[0]) | (ja == 0)) & ((xa < ra[3]) | (ja == e.floor.n_pieces - 1)) & (e.floor.uniform != 0);
+            const bool okb = ((xb >= rb[0]) | (jb == 0)) & ((xb < rb[3]) | (jb == e.ceil.n_pieces - 1)) & (e.ceil.uniform != 0);
+            if (!(oka & okb)) {
+                ja = rt2d_fix_piece(tab, e.floor, xa, ja);
+                jb = rt2d_fix_piece(tab, e.ceil, xb, jb);
+                auto pa = tab + e.floor.off + ja * 3;
+                auto pb = tab + e.ceil.off + jb * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ra[k] = pa[k]; rb[k] = pb[k]; }
+            }
+        }
+        const double z_floor = ra[1] * (xa - ra[0]) + ra[2];
+        const double z_ceil = rb[1] * (xb - rb[0]) + rb[2];
+        if (want_margin) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
 
         const bool hit_floor = z_new < z_floor;
         const bool hit_ceil = !hit_floor && (z_new > z_ceil);
-        if (hit_floor || hit_ceil) {                                      // ray.py:176-220
+        const bool rebound = hit_floor || hit_ceil;
+        if (rebound) {                                                    // ray.py:176-220
             const DevTable slope_t = hit_floor ? cold->dx_floor : cold->dx_ceil;
             double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : rt2d_eval_lin(tab, e.ceil, x);
             x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
@@ -288,8 +322,8 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             double n0 = hit_floor ? -1 * u1 : u1;
             double n1 = hit_floor ? u0 : -1 * u0;
             double ku = kx * u0 + kz * u1, kn = kx * n0 + kz * n1;
-            double rx = ku * u0 - kn * n0, rz = ku * u1 - kn * n1;
-            kx = rx; kz = rz;
+            double rx = ku * u0 - kn * n0, rzz = ku * u1 - kn * n1;
+            kx = rx; kz = rzz;
             double q = kz / kx;
             double ang = 1 / sqrt(1 + q * q);                              // ray.py:184,207 (cos of grazing angle)
             const Rt2dRayOut& co = cold->out;
@@ -311,17 +345,19 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                                       : rt2d_refcoef_surface(wavelength, ang);
                 g_pend = 10 * log10(rc);
             }
-            if (POST) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+            if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             const int nrm = cold->n_rebounds_max;
             if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended
                 rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);
-                if (POST) {
+                if (FULL) {
                     double ddx = x_new - x, ddz = z_new - z;
                     double dL = sqrt(ddx * ddx + ddz * ddz);
                     L += dL; T += dL / c_pt;
+                    if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
+                }
+                if (POST >= 1) {
                     min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
                     min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
-                    if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
                 }
                 if (WRITE && n_pts < room) {
                     px += RT2D_WAVE; pz += RT2D_WAVE;
@@ -342,10 +378,10 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
 
         // accept the point (ray.py:235-247)
         bool cut = false;
-        if (POST || CUTOFF) {
+        if (FULL || CUTOFF) {
             double ddx = x_new - x, ddz = z_new - z;
             double dL = sqrt(ddx * ddx + ddz * ddz);                       // ray.py:271
-            if (POST) { L += dL; T += dL / c_pt; }                         // ray.py:272-275
+            if (FULL) { L += dL; T += dL / c_pt; }                         // ray.py:272-275
             if (CUTOFF) {
                 double rec[20];
                 rt2d_lookup<19>(gtab, e.absorb, z, rec);                   // factors at the START of the segment, ray.py:346
@@ -356,14 +392,20 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             }
         }
         x = x_new; z = z_new;
-        double dz_c;
-        rt2d_eval_cz(tab, e.cz, z, c, dz_c);
-        if (POST) {
-            c_pt = c;
+        {
+            // the record prefetched for z_new stands unless a rebound moved the point or the guess was off
+            const bool okz = ((z >= rz[0]) | (jz == 0)) & ((z < rz[7]) | (jz == e.cz.n_pieces - 1)) & (e.cz.uniform != 0) & !rebound;
+            if (!okz) rt2d_lookup<7>(tab, e.cz, z, rz);
+        }
+        const double dzr = z - rz[0];
+        c = rt2d_quad_of(rz, dzr, 0);
+        const double dz_c = rt2d_quad_of(rz, dzr, 1);
+        if (FULL || (WRITE && pc)) c_pt = c;
+        if (POST >= 1) {
             min_x = fmin(min_x, x); max_x = fmax(max_x, x);
             min_z = fmin(min_z, z); max_z = fmax(max_z, z);
-            if (has_target) tt.add(x, z, T, n_pts, tx);
         }
+        if (FULL && has_target) tt.add(x, z, T, n_pts, tx);
         if (WRITE && n_pts < room) {
             px += RT2D_WAVE; pz += RT2D_WAVE;
             *px = x; *pz = z;
@@ -387,8 +429,10 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     if (o.stop_code) o.stop_code[r] = stop;
     if (o.n_rebounds) o.n_rebounds[r] = n_reb;
     if (o.status) o.status[r] = status;
-    if (POST) {
+    if (POST >= 1) {
         if (o.range) { o.range[r] = min_x; o.range[n + r] = min_z; o.range[2 * n + r] = max_x; o.range[3 * n + r] = max_z; }
+    }
+    if (FULL) {
         if (o.L_end) o.L_end[r] = L;
         if (o.T_end) o.T_end[r] = T;
         if (o.margin) o.margin[r] = margin;
@@ -1060,6 +1104,10 @@ int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
     Rt2dTable cz[2] = {d->c, d->dz_c};
     if ((rc = pack_table(blob, cz, 2, 3, 0, &e.cz, "c/dz_c"))) { delete env; return rc; }
     e.cz_doubles = (int32_t)blob.size();
+    if (d->floor.oob != RT2D_OOB_CLAMP || d->ceil.oob != RT2D_OOB_CLAMP) {
+        delete env;
+        return fail("rt2d_env_create: the floor and ceil tables must use RT2D_OOB_CLAMP (the stepping kernel clamps them unconditionally)");
+    }
     if ((rc = pack_table(blob, &d->floor, 1, 2, 0, &e.floor, "floor"))) { delete env; return rc; }
     if ((rc = pack_table(blob, &d->ceil, 1, 2, 0, &e.ceil, "ceil"))) { delete env; return rc; }
     if ((rc = pack_table(blob, &d->dx_floor, 1, 3, 0, &e.dx_floor, "dx_floor"))) { delete env; return rc; }
@@ -1099,11 +1147,12 @@ int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out) {
 #define RT2D_LDS_BUDGET (152 * 1024)
 
 extern "C++" {
-static bool wants_post(const Rt2dRayOut& o) {
-    return o.range || o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin;
+static int post_level(const Rt2dRayOut& o) {
+    if (o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin) return 2;
+    return o.range ? 1 : 0;
 }
 
-template <bool WRITE, bool POST, bool CUTOFF>
+template <bool WRITE, int POST, bool CUTOFF>
 static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t stream) {
     CastArgs a = a_in;
     const int64_t n = a.n;
@@ -1148,8 +1197,12 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
 
 template <bool WRITE>
 static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream) {
-    if (a.p.power_cutoff > 0) return launch_cast2<WRITE, true, true>(env, a, stream);
-    return wants_post(a.out) ? launch_cast2<WRITE, true, false>(env, a, stream) : launch_cast2<WRITE, false, false>(env, a, stream);
+    if (a.p.power_cutoff > 0) return launch_cast2<WRITE, 2, true>(env, a, stream);
+    switch (post_level(a.out)) {
+        case 2: return launch_cast2<WRITE, 2, false>(env, a, stream);
+        case 1: return launch_cast2<WRITE, 1, false>(env, a, stream);
+        default: return launch_cast2<WRITE, 0, false>(env, a, stream);
+    }
 }
 }  // extern "C++"
 

@@ -26,7 +26,8 @@ def _as_surface_table(obj, x_min, x_max, n_samples):
     if isinstance(obj, PPTable):
         if obj.order != 2:
             raise ValueError('floor / ceiling tables must be piecewise linear (order 2)')
-        return obj
+        # the stepping kernel clamps both surfaces outside their breaks
+        return obj if obj.oob == OOB_CLAMP else PPTable(obj.breaks, obj.coef, oob=OOB_CLAMP)
     if isinstance(obj, (tuple, list)) and len(obj) == 2 and np.ndim(obj[0]) == 1:
         return linear_interp_table(obj[0], obj[1], oob=OOB_CLAMP)
     if callable(obj):

@@ -93,9 +93,7 @@ class RayFan:
             self.n_rebounds = torch.empty(n, **i32)
             self.status = torch.empty(n, **i32)
             self.range = torch.empty((4, n), **f64)
-            self.L_end = torch.empty(n, **f64)
-            self.T_end = torch.empty(n, **f64)
-            self.margin = torch.empty(n, **f64)
+            self._scalars = None
             self.dist = torch.full((n,), float('nan'), **f64)
             self.step_target = torch.full((n,), -1, **i32)
             self.T_target = torch.full((n,), float('nan'), **f64)
@@ -110,8 +108,9 @@ class RayFan:
                 out = _lib.Rt2dRayOut()
                 out.n_pts, out.stop_code = self.n_pts.data_ptr(), self.stop_code.data_ptr()
                 out.n_rebounds, out.status = self.n_rebounds.data_ptr(), self.status.data_ptr()
-                out.range, out.L_end, out.T_end = self.range.data_ptr(), self.L_end.data_ptr(), self.T_end.data_ptr()
-                out.margin = self.margin.data_ptr()
+                # the bounding box is all the heat-map pipeline needs of the post-pass; L_end / T_end / margin are
+                # produced on demand (_lazy_scalars) so that the main cast does not carry them through every step
+                out.range = self.range.data_ptr()
                 if self.target is not None:
                     out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
                     out.T_target = self.T_target.data_ptr()
@@ -197,6 +196,38 @@ class RayFan:
             cast_write(out, self.rebound_cap, self.tile_off, self.X, self.Z, self.Cpt)
             self._out = out
             self.passes = 'count+store'
+
+    # -- scalars produced on demand ---------------------------------------------------------------
+    def _lazy_scalars(self):
+        """L_end, T_end (ray.py:272-275, last elements) and the decision margin: one more pass of the stepping kernel
+        without stores.  The kernel is deterministic, so these belong to exactly the rays of the main cast."""
+        if self._scalars is None:
+            torch = _torch()
+            with torch.cuda.device(self.device):
+                f64 = dict(dtype=torch.float64, device=self.device)
+                d = {k: torch.empty(self.n, **f64) for k in ('L_end', 'T_end', 'margin')}
+                if self.n:
+                    out = _lib.Rt2dRayOut()
+                    out.L_end, out.T_end, out.margin = d['L_end'].data_ptr(), d['T_end'].data_ptr(), d['margin'].data_ptr()
+                    src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
+                    p = self._params(0)
+                    _lib.check(_lib.lib().rt2d_cast_count(self.env.device_handle(self.device.index), self.angles_dev.data_ptr(),
+                                                         self.n, src, C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]),
+                                                         C.byref(out), torch.cuda.current_stream().cuda_stream))
+            self._scalars = d
+        return self._scalars
+
+    @property
+    def L_end(self):
+        return self._lazy_scalars()['L_end']
+
+    @property
+    def T_end(self):
+        return self._lazy_scalars()['T_end']
+
+    @property
+    def margin(self):
+        return self._lazy_scalars()['margin']
 
     # -- host copies ------------------------------------------------------------------------------
     def host(self, name):
@@ -377,7 +408,6 @@ class Ray2D:
         rng = fan.host('range')
         self.range_min = np.array([rng[0, i], rng[1, i]])
         self.range_max = np.array([rng[2, i], rng[3, i]])
-        self.decision_margin = float(fan.host('margin')[i])
         if fan.target is not None:
             self.dist_to_target = np.float64(fan.host('dist')[i])
             self.step_target = int(fan.host('step_target')[i])
@@ -385,6 +415,11 @@ class Ray2D:
         else:
             self.step_target = None
             self.T_target = None
+
+    @property
+    def decision_margin(self):
+        """Smallest distance [m] by which any comparison of the loop was decided (diagnostic, not in the reference)."""
+        return float(self._fan.host('margin')[self._i])
 
     def __repr__(self):
         return f'Ray2D ({self.source}, {self.angle})'
