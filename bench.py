@@ -115,9 +115,10 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(with_log(out)),
                                      off0.data_ptr(), X0.data_ptr(), Z0.data_ptr(), None, stream))
         if ev: ev[3].record()
-        _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), C.byref(total), stream))
-        if int(tile_off.diff().max().item()) <= room * 64 and not bool((status == -2).any().item()):
-            total = int(total.value)
+        _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), None, stream))
+        tot, longest, log_full = torch.stack((tile_off[-1], tile_off.diff().max(), (status == -2).any().to(torch.int64))).tolist()
+        if longest <= room * 64 and not log_full:
+            total = int(tot)
             X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
             _lib.check(L.rt2d_traj_compact(off0.data_ptr(), tile_off.data_ptr(), n, X0.data_ptr(), Z0.data_ptr(), None,
                                            X.data_ptr(), Z.data_ptr(), None, stream))

@@ -684,63 +684,105 @@ __global__ void __launch_bounds__(256) rt2d_gain_dg_kernel(const GainArgs a) {
     }
 }
 
-#define GAIN_SCAN_AHEAD 16
-__global__ void __launch_bounds__(64) rt2d_gain_scan_kernel(const GainArgs a) {
-    // per lane: cumulative rebound loss after rebound k and the first point that carries it, kept in LDS so that the
-    // scan loop below issues no memory instruction other than its own loads and stores of G
-    extern __shared__ __attribute__((aligned(16))) double s_loss[];        // [cap][64] doubles, then [cap][64] ints
-    int* s_at = reinterpret_cast<int*>(s_loss + (size_t)a.rebound_cap * RT2D_WAVE);
-    const int lane = threadIdx.x;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n) return;
+// One workgroup of 16 waves per (tile, frequency).  All waves move the tile through LDS in chunks of
+// GAIN_SCAN_ROWS steps with coalesced loads and stores (the next chunk is already in flight in registers); wave 0
+// alone runs the 64 running sums over the chunk in LDS, so the serial chain never waits on global memory.
+#define GAIN_SCAN_ROWS 64
+#define GAIN_SCAN_THREADS 1024
+#define GAIN_SCAN_PER_THREAD (GAIN_SCAN_ROWS * RT2D_WAVE / GAIN_SCAN_THREADS)
+__global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const GainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_buf[];          // [ROWS][64] chunk, then the loss table
+    double* s_loss = s_buf + GAIN_SCAN_ROWS * RT2D_WAVE;                   // [cap][64] cumulative rebound loss
+    int* s_at = reinterpret_cast<int*>(s_loss + (size_t)a.rebound_cap * RT2D_WAVE);   // [cap][64] first point carrying it
+    const int lane = threadIdx.x & 63;
+    const bool scanner = threadIdx.x < RT2D_WAVE;
+    const int64_t tile = blockIdx.x;
+    const int64_t r = tile * RT2D_WAVE + lane;
     const int fi = blockIdx.y;
-    const double fr = a.freqs[fi];
-    const double* gtab = a.blob + a.env.gain_off;
-    const int np = a.n_pts[r];
-    const int64_t base = a.tile_off[r >> 6] + (r & 63);
-    double* G = a.G + (int64_t)fi * a.total;
-    const int nreb = min(a.n_rebounds[r], a.rebound_cap);
+    const int64_t t0 = a.tile_off[tile];
+    const int64_t len = a.tile_off[tile + 1] - t0;                          // 64 * steps of the longest ray of the tile
+    double* G = a.G + (int64_t)fi * a.total + t0;
+    // rebound losses of the tile's rays (ray.py:350-362): every (rebound, ray) pair on its own thread -- each costs a
+    // handful of dependent loads, a sincos, a log10 -- then wave 0 turns them into running sums per ray
+    const int nreb = (r < a.n) ? min(a.n_rebounds[r], a.rebound_cap) : 0;
     {
-        double A = 0.0;
-        for (int k = 0; k < nreb; ++k) {                                        // ray.py:350-362
-            int64_t kk = (int64_t)k * a.n + r;
-            double wavelength = a.reb_velocity[kk] / fr;
-            double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
-                ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, a.env.imp, a.reb_pos_z[kk], nullptr))
-                : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
-            A += 10 * log10(rc);
-            s_loss[k * RT2D_WAVE + lane] = A;
-            s_at[k * RT2D_WAVE + lane] = a.reb_step[kk] + 1;
+        const double fr = a.freqs[fi];
+        const double* gtab = a.blob + a.env.gain_off;
+        for (int k = threadIdx.x >> 6; k < a.rebound_cap; k += GAIN_SCAN_THREADS / RT2D_WAVE) {
+            if (k < nreb) {
+                int64_t kk = (int64_t)k * a.n + r;
+                double wavelength = a.reb_velocity[kk] / fr;
+                double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
+                    ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, a.env.imp, a.reb_pos_z[kk], nullptr))
+                    : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
+                s_loss[k * RT2D_WAVE + lane] = 10 * log10(rc);
+                s_at[k * RT2D_WAVE + lane] = a.reb_step[kk] + 1;
+            }
         }
     }
+    __syncthreads();
+    const int np = (r < a.n) ? a.n_pts[r] : 0;          // of the ray in this thread's column (lane == column for every element)
+    if (scanner) {
+        double A = 0.0;
+        for (int k = 0; k < nreb; ++k) { A += s_loss[k * RT2D_WAVE + lane]; s_loss[k * RT2D_WAVE + lane] = A; }
+    }
+    __syncthreads();
+    // Division of labour per chunk: every thread zeroes the entries past its ray's end while filling LDS, wave 0 runs
+    // the bare running sums S (one dependent add per point), and every thread adds the rebound loss A of its point on
+    // the way out: G = S + A as in the one-pass kernel.  A thread meets its column's points in increasing order, so the
+    // loss in force is a cursor into the column's table.
     int next_reb = 0;
     int next_reb_at = (nreb > 0) ? s_at[lane] : 0x7fffffff;
-    double S = 0.0, A = 0.0;
-    // two register buffers: the loads of the next GAIN_SCAN_AHEAD points are in flight while this batch is summed
-    double cur[GAIN_SCAN_AHEAD], nxt[GAIN_SCAN_AHEAD];
-    const int last = max(np - 1, 0);
+    double A = 0.0, S = 0.0;
+    const int row0 = threadIdx.x >> 6;                  // row of this thread's first element inside a chunk
+    constexpr int ROW_STEP = GAIN_SCAN_THREADS / RT2D_WAVE;
+    const int64_t chunk = (int64_t)GAIN_SCAN_ROWS * RT2D_WAVE;
+    const int64_t last = len - 1;
+    double regs[GAIN_SCAN_PER_THREAD];
 #pragma unroll
-    for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) cur[u] = G[base + (int64_t)min(1 + u, last) * RT2D_WAVE];
-    for (int s0 = 1; s0 < np; s0 += GAIN_SCAN_AHEAD) {
+    for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k) regs[k] = G[min((int64_t)(threadIdx.x + GAIN_SCAN_THREADS * k), last)];
+    for (int64_t c0 = 0; c0 < len; c0 += chunk) {
+        const int s_first = (int)(c0 >> 6);
 #pragma unroll
-        for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) nxt[u] = G[base + (int64_t)min(s0 + GAIN_SCAN_AHEAD + u, last) * RT2D_WAVE];
-#pragma unroll
-        for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) {
-            const int s = s0 + u;
-            while (s < np && s >= next_reb_at) {                                // a loss that starts past the end never applies
-                A = s_loss[next_reb * RT2D_WAVE + lane];
-                ++next_reb;
-                next_reb_at = (next_reb < nreb) ? s_at[next_reb * RT2D_WAVE + lane] : 0x7fffffff;
-            }
-            if (s < np) {
-                S += cur[u];                                                    // ray.py:347
-                G[base + (int64_t)s * RT2D_WAVE] = S + A;
-            }
+        for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k) {
+            const int sx = s_first + row0 + ROW_STEP * k;
+            s_buf[threadIdx.x + GAIN_SCAN_THREADS * k] = (sx >= 1 && sx < np) ? regs[k] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < GAIN_SCAN_AHEAD; ++u) cur[u] = nxt[u];
+        for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k)                      // next chunk on its way during the sums
+            regs[k] = G[min(c0 + chunk + threadIdx.x + GAIN_SCAN_THREADS * k, last)];
+        __syncthreads();
+        if (scanner) {
+            for (int rb = 0; rb < GAIN_SCAN_ROWS; rb += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = s_buf[(rb + u) * RT2D_WAVE + lane];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { S += v[u]; v[u] = S; }       // ray.py:347
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s_buf[(rb + u) * RT2D_WAVE + lane] = v[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k) {
+            const int sx = s_first + row0 + ROW_STEP * k;
+            if (sx < np) {
+                while (sx >= next_reb_at) {
+                    A = s_loss[next_reb * RT2D_WAVE + lane];
+                    ++next_reb;
+                    next_reb_at = (next_reb < nreb) ? s_at[next_reb * RT2D_WAVE + lane] : 0x7fffffff;
+                }
+                G[c0 + threadIdx.x + GAIN_SCAN_THREADS * k] = s_buf[threadIdx.x + GAIN_SCAN_THREADS * k] + A;
+            }
+        }
+        __syncthreads();
     }
-    if (a.G_end) a.G_end[(int64_t)fi * a.n + r] = S + A;
+    if (scanner && r < a.n && a.G_end) {
+        double A_end = 0.0;                              // loss in force at the last point
+        for (int k = 0; k < nreb && s_at[k * RT2D_WAVE + lane] <= np - 1; ++k) A_end = s_loss[k * RT2D_WAVE + lane];
+        a.G_end[(int64_t)fi * a.n + r] = S + A_end;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -822,6 +864,7 @@ struct HeatArgs {
     int32_t* work;                                  // [0] = number of rays left to the general kernel, [2 + k] = their ids
     HeatGeom geo; int64_t nx, nz;
     double* H; int64_t* n_dropped; int32_t cap;     // cap: hash slots per ray, power of two
+    int32_t cell_cap;                               // points per ray whose cells are cached in LDS
 };
 
 // Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
@@ -934,76 +977,112 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     }
 }
 
+// General path: one wave per ray, any trajectory.  The cell of every point is computed once into LDS (rays longer than
+// the cell cache recompute it from global memory); "last write wins" is resolved by an LDS hash cell -> last step, in
+// partitions when the ray has more candidate cells than half the hash.
 __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
+    int32_t* s_cell = reinterpret_cast<int32_t*>(s_hash + a.cap);
     const int lane = threadIdx.x;
     const int64_t size = a.nx * a.nz;
     const uint32_t mask = (uint32_t)a.cap - 1;
     // rays come either from the queue the fast kernel filled (work != NULL) or straight from the mask
     const int64_t n_items = a.work ? (int64_t)a.work[0] : a.n;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
-    if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
-    const int np = a.n_pts[r];
-    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+        const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
+        if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
+        const int np = a.n_pts[r];
+        const int64_t base = a.tile_off[r >> 6] + (r & 63);
+        const bool cached = np <= a.cell_cap;
+        auto cell_global = [&](int s) -> int32_t {
+            const int64_t o = base + (int64_t)s * RT2D_WAVE;
+            return (int32_t)rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
+        };
+        auto cell_at = [&](int s) -> int32_t { return cached ? s_cell[s] : cell_global(s); };
 
-    // pass 0: count run ends (candidates) and dropped points
-    int n_cand = 0, n_drop = 0;
-    for (int s = lane; s < np; s += RT2D_WAVE) {
-        int64_t o = base + (int64_t)s * RT2D_WAVE;
-        int64_t cell = rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
-        int64_t nxt = -2;
-        if (s + 1 < np) nxt = rt2d_cell(a.geo, a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.nz, size);
-        if (cell < 0) ++n_drop; else if (nxt != cell) ++n_cand;
-    }
-    for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_xor(n_cand, off); n_drop += __shfl_xor(n_drop, off); }
-    if (lane == 0 && n_drop && a.n_dropped) atomicAdd((unsigned long long*)a.n_dropped, (unsigned long long)n_drop);
-    const int parts = max(1, (4 * n_cand + a.cap - 1) / a.cap);        // expected load <= 1/4 per partition
-
-    for (int part = 0; part < parts; ++part) {
-        for (int i = lane; i < a.cap; i += RT2D_WAVE) s_hash[i] = HM_EMPTY;
-        __syncthreads();
-        // pass A: cell -> max step
-        for (int s = lane; s < np; s += RT2D_WAVE) {
-            int64_t o = base + (int64_t)s * RT2D_WAVE;
-            int64_t cell = rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
-            if (cell < 0) continue;
-            if (s + 1 < np && rt2d_cell(a.geo, a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.nz, size) == cell) continue;
-            uint32_t h = rt2d_hash32((uint32_t)cell);
-            if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
-            unsigned long long packed = ((unsigned long long)(uint32_t)cell << 32) | (uint32_t)s;
-            uint32_t slot = h & mask;
-            for (int probe = 0; probe < a.cap; ++probe) {
-                unsigned long long old = atomicCAS(&s_hash[slot], HM_EMPTY, packed);
-                if (old == HM_EMPTY) break;
-                if ((old >> 32) == (unsigned long long)(uint32_t)cell) { atomicMax(&s_hash[slot], packed); break; }
-                slot = (slot + 1) & mask;
+        // pass 0: cells (four independent loads per lane in flight), dropped points
+        int n_drop = 0;
+        for (int s0 = 0; s0 < np; s0 += 4 * RT2D_WAVE) {
+            double xs[4], zs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sc = min(s0 + u * RT2D_WAVE + lane, np - 1);
+                const int64_t o = base + (int64_t)sc * RT2D_WAVE;
+                xs[u] = a.X[o]; zs[u] = a.Z[o];
             }
-        }
-        __syncthreads();
-        // pass B: the step that owns its cell deposits (simulation.py:129-131)
-        for (int s = lane; s < np; s += RT2D_WAVE) {
-            int64_t o = base + (int64_t)s * RT2D_WAVE;
-            int64_t cell = rt2d_cell(a.geo, a.X[o], a.Z[o], a.nz, size);
-            if (cell < 0) continue;
-            if (s + 1 < np && rt2d_cell(a.geo, a.X[o + RT2D_WAVE], a.Z[o + RT2D_WAVE], a.nz, size) == cell) continue;
-            uint32_t h = rt2d_hash32((uint32_t)cell);
-            if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
-            uint32_t slot = h & mask;
-            for (int probe = 0; probe < a.cap; ++probe) {
-                unsigned long long cur = s_hash[slot];
-                if (cur == HM_EMPTY) break;
-                if ((cur >> 32) == (unsigned long long)(uint32_t)cell) {
-                    if ((uint32_t)cur == (uint32_t)s) {
-                        atomicAdd(&a.H[cell], rt2d_heat_val(a.G[o]));          // ray.py:317, simulation.py:129
-                    }
-                    break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sx = s0 + u * RT2D_WAVE + lane;
+                if (sx < np) {
+                    const int32_t cell = (int32_t)rt2d_cell(a.geo, xs[u], zs[u], a.nz, size);
+                    if (cached) s_cell[sx] = cell;
+                    n_drop += cell < 0;
                 }
-                slot = (slot + 1) & mask;
             }
         }
         __syncthreads();
-    }
+        int n_cand = 0;
+        for (int sx = lane; sx < np; sx += RT2D_WAVE) {
+            const int32_t cell = cell_at(sx);
+            const int32_t nxt = (sx + 1 < np) ? cell_at(sx + 1) : -2;
+            n_cand += (cell >= 0) & (nxt != cell);
+        }
+        for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_xor(n_cand, off); n_drop += __shfl_xor(n_drop, off); }
+        if (lane == 0 && n_drop && a.n_dropped) atomicAdd((unsigned long long*)a.n_dropped, (unsigned long long)n_drop);
+        const int parts = max(1, (2 * n_cand + a.cap - 1) / a.cap);        // load factor <= 1/2 per partition
+
+        for (int part = 0; part < parts; ++part) {
+            for (int i = lane; i < a.cap; i += RT2D_WAVE) s_hash[i] = HM_EMPTY;
+            __syncthreads();
+            // pass A: cell -> max step
+            for (int sx = lane; sx < np; sx += RT2D_WAVE) {
+                const int32_t cell = cell_at(sx);
+                if (cell < 0) continue;
+                if (sx + 1 < np && cell_at(sx + 1) == cell) continue;
+                const uint32_t h = rt2d_hash32((uint32_t)cell);
+                if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
+                const unsigned long long packed = ((unsigned long long)(uint32_t)cell << 32) | (uint32_t)sx;
+                uint32_t slot = h & mask;
+                for (int probe = 0; probe < a.cap; ++probe) {
+                    unsigned long long old = atomicCAS(&s_hash[slot], HM_EMPTY, packed);
+                    if (old == HM_EMPTY) break;
+                    if ((old >> 32) == (unsigned long long)(uint32_t)cell) { atomicMax(&s_hash[slot], packed); break; }
+                    slot = (slot + 1) & mask;
+                }
+            }
+            __syncthreads();
+            // pass B: the step that owns its cell deposits (simulation.py:129-131); eight points per lane at a time so
+            // that their gain loads travel together
+            for (int s0 = 0; s0 < np; s0 += 8 * RT2D_WAVE) {
+                int32_t own[8]; double gv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sx = s0 + u * RT2D_WAVE + lane;
+                    own[u] = -1;
+                    gv[u] = 0.0;
+                    if (sx >= np) continue;
+                    const int32_t cell = cell_at(sx);
+                    if (cell < 0) continue;
+                    if (sx + 1 < np && cell_at(sx + 1) == cell) continue;
+                    const uint32_t h = rt2d_hash32((uint32_t)cell);
+                    if ((int)((h >> 8) % (uint32_t)parts) != part) continue;
+                    uint32_t slot = h & mask;
+                    for (int probe = 0; probe < a.cap; ++probe) {
+                        const unsigned long long cur = s_hash[slot];
+                        if (cur == HM_EMPTY) break;
+                        if ((cur >> 32) == (unsigned long long)(uint32_t)cell) {
+                            if ((uint32_t)cur == (uint32_t)sx) { own[u] = cell; gv[u] = a.G[base + (int64_t)sx * RT2D_WAVE]; }
+                            break;
+                        }
+                        slot = (slot + 1) & mask;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (own[u] >= 0) atomicAdd(&a.H[own[u]], rt2d_heat_val(gv[u]));     // ray.py:317, simulation.py:129
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1321,8 +1400,8 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain: absorption tables do not fit in LDS");
     const int fch = n_freqs >= 8 ? 8 : (n_freqs >= 3 ? 4 : n_freqs);      // frequencies per lane: amortises the 6 table evals
     const char* tp = getenv("RT2D_GAIN_TWO_PHASE_MAX_RAYS");              // tests force either path with this
-    const size_t scan_lds = (size_t)(rebound_cap > 0 ? rebound_cap : 1) * RT2D_WAVE * 12;
-    if (G && n <= (tp ? atoll(tp) : 64 * 512) && scan_lds <= 64 * 1024) {
+    const size_t scan_lds = (size_t)GAIN_SCAN_ROWS * RT2D_WAVE * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * RT2D_WAVE * 12;
+    if (G && n <= (tp ? atoll(tp) : 64 * 512) && scan_lds <= RT2D_LDS_BUDGET) {
         // small fan: per-point dG on the whole chip, then the running sums (see rt2d_gain_dg_kernel)
         const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
         const unsigned split = (unsigned)(n_tiles >= 512 ? 4 : (2048 + n_tiles - 1) / n_tiles);
@@ -1331,7 +1410,8 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
                                     : fch == 2 ? rt2d_gain_dg_kernel<2> : rt2d_gain_dg_kernel<1>;
         HIP_OK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k1, grid1, dim3(256), lds, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(rt2d_gain_scan_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs), dim3(64), scan_lds, (hipStream_t)stream, a);
+        HIP_OK(hipFuncSetAttribute((const void*)rt2d_gain_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        hipLaunchKernelGGL(rt2d_gain_scan_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs), dim3(GAIN_SCAN_THREADS), scan_lds, (hipStream_t)stream, a);
         HIP_OK(hipGetLastError());
         return 0;
     }
@@ -1373,7 +1453,7 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     a.geo.inv_rx = 1.0 / res[0]; a.geo.inv_rz = 1.0 / res[1];
     a.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
     a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
-    a.cap = 4096;
+    a.cap = 4096; a.cell_cap = 4096;
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
     // below ~16k rays the latter finishes first
     static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 16384;
@@ -1391,7 +1471,7 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     }
     // general kernel: everything (no workspace) or what the fast kernel queued; blocks stride over the items
     const int64_t blocks = n < 16384 ? n : 16384;
-    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(RT2D_WAVE), (size_t)a.cap * 8, stream, a);
+    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(RT2D_WAVE), (size_t)a.cap * 8 + (size_t)a.cell_cap * 4, stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -165,9 +165,12 @@ class RayFan:
                 Z0 = torch.empty(n_tiles * room * TILE, **f64)
                 C0 = torch.empty(n_tiles * room * TILE, **f64) if store_c else None
                 cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
-                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), C.byref(total), stream))
-                fitted = int(total.value) <= n_tiles * room * TILE and int(self.tile_off.diff().max().item()) <= room * TILE
-                if fitted and not bool((self.status == _lib.RAY_ERR_REBOUND_LOG).any().item()):
+                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), None, stream))
+                # one device -> host read: total points, longest tile, "a rebound log overflowed"
+                tot, longest, log_full = torch.stack((self.tile_off[-1], self.tile_off.diff().max(),
+                                                      (self.status == _lib.RAY_ERR_REBOUND_LOG).any().to(torch.int64))).tolist()
+                if longest <= room * TILE and not log_full:
+                    total.value = tot
                     self.total = int(total.value)
                     self.X = torch.empty(self.total, **f64)
                     self.Z = torch.empty(self.total, **f64)
