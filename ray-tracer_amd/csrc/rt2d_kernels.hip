@@ -282,18 +282,28 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) rz[k] = pzr[k];
         }
-        if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
-
-        // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
-        // clipped in x is still inside in z; the clipped point is NOT appended
-        if (x_new < e.range_min[0] || x_new > e.range_max[0]) {
-            int out = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
-            if (out == 1 || out == 2) { stop = out; break; }
+        // The common step -- inside the rectangle, between floor and surface, all three guessed pieces right -- is
+        // recognised by ONE predicate and skips every branch of the general case below; when the predicate fails the
+        // general case runs in the reference's order (ray.py:162-230) and none of its branches would fire otherwise.
+        const bool oka = ((xa >= ra[0]) | (ja == 0)) & ((xa < ra[3]) | (ja == e.floor.n_pieces - 1)) & (e.floor.uniform != 0);
+        const bool okb = ((xb >= rb[0]) | (jb == 0)) & ((xb < rb[3]) | (jb == e.ceil.n_pieces - 1)) & (e.ceil.uniform != 0);
+        const bool okz = ((z_new >= rz[0]) | (jz == 0)) & ((z_new < rz[7]) | (jz == e.cz.n_pieces - 1)) & (e.cz.uniform != 0);
+        double z_floor = ra[1] * (xa - ra[0]) + ra[2];
+        double z_ceil = rb[1] * (xb - rb[0]) + rb[2];
+        const bool general = !(oka & okb & okz) | (x_new < e.range_min[0]) | (x_new > e.range_max[0])
+                           | (z_new < e.range_min[1]) | (z_new > e.range_max[1]) | (z_new < z_floor) | (z_new > z_ceil);
+        if (want_margin && !general) {
+            margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+            margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
         }
-
-        {
-            const bool oka = ((xa >= ra[0]) | (ja == 0)) & ((xa < ra[3]) | (ja == e.floor.n_pieces - 1)) & (e.floor.uniform != 0);
-            const bool okb = ((xb >= rb[0]) | (jb == 0)) & ((xb < rb[3]) | (jb == e.ceil.n_pieces - 1)) & (e.ceil.uniform != 0);
+        if (general) {
+            if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+            // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
+            // clipped in x is still inside in z; the clipped point is NOT appended
+            if (x_new < e.range_min[0] || x_new > e.range_max[0]) {
+                int out = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
+                if (out == 1 || out == 2) { stop = out; break; }
+            }
             if (!(oka & okb)) {
                 ja = rt2d_fix_piece(tab, e.floor, xa, ja);
                 jb = rt2d_fix_piece(tab, e.ceil, xb, jb);
@@ -301,79 +311,81 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                 auto pb = tab + e.ceil.off + jb * 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { ra[k] = pa[k]; rb[k] = pb[k]; }
+                z_floor = ra[1] * (xa - ra[0]) + ra[2];
+                z_ceil = rb[1] * (xb - rb[0]) + rb[2];
             }
-        }
-        const double z_floor = ra[1] * (xa - ra[0]) + ra[2];
-        const double z_ceil = rb[1] * (xb - rb[0]) + rb[2];
-        if (want_margin) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
+            if (want_margin) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
 
-        const bool hit_floor = z_new < z_floor;
-        const bool hit_ceil = !hit_floor && (z_new > z_ceil);
-        const bool rebound = hit_floor || hit_ceil;
-        if (rebound) {                                                    // ray.py:176-220
-            const DevTable slope_t = hit_floor ? cold->dx_floor : cold->dx_ceil;
-            double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : rt2d_eval_lin(tab, e.ceil, x);
-            x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
-            z_new = hit_floor ? z_floor : z_ceil;
-            bool ok;
-            double s = rt2d_eval_quad(tab, slope_t, x_new, &ok);
-            if (!ok) { status = RT2D_RAY_ERR_INTERP; break; }
-            double u0 = 1.0, u1 = s;
-            double n0 = hit_floor ? -1 * u1 : u1;
-            double n1 = hit_floor ? u0 : -1 * u0;
-            double ku = kx * u0 + kz * u1, kn = kx * n0 + kz * n1;
-            double rx = ku * u0 - kn * n0, rzz = ku * u1 - kn * n1;
-            kx = rx; kz = rzz;
-            double q = kz / kx;
-            double ang = 1 / sqrt(1 + q * q);                              // ray.py:184,207 (cos of grazing angle)
-            const Rt2dRayOut& co = cold->out;
-            if (n_reb < cold->rebound_cap) {
-                int64_t k = (int64_t)n_reb * cold->n + r;
-                if (co.reb_step) co.reb_step[k] = i + 1;
-                if (co.reb_surface) co.reb_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
-                if (co.reb_velocity) co.reb_velocity[k] = c;
-                if (co.reb_angle) co.reb_angle[k] = ang;
-                if (co.reb_pos_x) co.reb_pos_x[k] = x;
-                if (co.reb_pos_z) co.reb_pos_z[k] = z;
-            } else if (co.reb_step) {
-                status = RT2D_RAY_ERR_REBOUND_LOG;
-            }
-            n_reb += 1;
-            if (CUTOFF) {                                                   // ray.py:350-362; applies from the NEXT point on
-                double wavelength = c / p.cutoff_freq;
-                double rc = hit_floor ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, e.imp, z, nullptr))
-                                      : rt2d_refcoef_surface(wavelength, ang);
-                g_pend = 10 * log10(rc);
-            }
-            if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
-            const int nrm = cold->n_rebounds_max;
-            if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended
-                rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);
-                if (FULL) {
-                    double ddx = x_new - x, ddz = z_new - z;
-                    double dL = sqrt(ddx * ddx + ddz * ddz);
-                    L += dL; T += dL / c_pt;
-                    if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
+            const bool hit_floor = z_new < z_floor;
+            const bool hit_ceil = !hit_floor && (z_new > z_ceil);
+            const bool rebound = hit_floor || hit_ceil;
+            if (rebound) {                                                    // ray.py:176-220
+                const DevTable slope_t = hit_floor ? cold->dx_floor : cold->dx_ceil;
+                double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : rt2d_eval_lin(tab, e.ceil, x);
+                x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
+                z_new = hit_floor ? z_floor : z_ceil;
+                bool ok;
+                double s = rt2d_eval_quad(tab, slope_t, x_new, &ok);
+                if (!ok) { status = RT2D_RAY_ERR_INTERP; break; }
+                double u0 = 1.0, u1 = s;
+                double n0 = hit_floor ? -1 * u1 : u1;
+                double n1 = hit_floor ? u0 : -1 * u0;
+                double ku = kx * u0 + kz * u1, kn = kx * n0 + kz * n1;
+                double rx = ku * u0 - kn * n0, rzz = ku * u1 - kn * n1;
+                kx = rx; kz = rzz;
+                double q = kz / kx;
+                double ang = 1 / sqrt(1 + q * q);                              // ray.py:184,207 (cos of grazing angle)
+                const Rt2dRayOut& co = cold->out;
+                if (n_reb < cold->rebound_cap) {
+                    int64_t k = (int64_t)n_reb * cold->n + r;
+                    if (co.reb_step) co.reb_step[k] = i + 1;
+                    if (co.reb_surface) co.reb_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+                    if (co.reb_velocity) co.reb_velocity[k] = c;
+                    if (co.reb_angle) co.reb_angle[k] = ang;
+                    if (co.reb_pos_x) co.reb_pos_x[k] = x;
+                    if (co.reb_pos_z) co.reb_pos_z[k] = z;
+                } else if (co.reb_step) {
+                    status = RT2D_RAY_ERR_REBOUND_LOG;
                 }
-                if (POST >= 1) {
-                    min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
-                    min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
+                n_reb += 1;
+                if (CUTOFF) {                                                   // ray.py:350-362; applies from the NEXT point on
+                    double wavelength = c / p.cutoff_freq;
+                    double rc = hit_floor ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, e.imp, z, nullptr))
+                                          : rt2d_refcoef_surface(wavelength, ang);
+                    g_pend = 10 * log10(rc);
                 }
-                if (WRITE && n_pts < room) {
-                    px += RT2D_WAVE; pz += RT2D_WAVE;
-                    *px = x_new; *pz = z_new;
-                    if (pc) { pc += RT2D_WAVE; *pc = rt2d_eval_c(tab, e.cz, z_new); }
+                if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
+                const int nrm = cold->n_rebounds_max;
+                if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended
+                    rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);
+                    if (FULL) {
+                        double ddx = x_new - x, ddz = z_new - z;
+                        double dL = sqrt(ddx * ddx + ddz * ddz);
+                        L += dL; T += dL / c_pt;
+                        if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
+                    }
+                    if (POST >= 1) {
+                        min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
+                        min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
+                    }
+                    if (WRITE && n_pts < room) {
+                        px += RT2D_WAVE; pz += RT2D_WAVE;
+                        *px = x_new; *pz = z_new;
+                        if (pc) { pc += RT2D_WAVE; *pc = rt2d_eval_c(tab, e.cz, z_new); }
+                    }
+                    n_pts += 1;
+                    stop = RT2D_STOP_MAX_REBOUNDS;
+                    break;
                 }
-                n_pts += 1;
-                stop = RT2D_STOP_MAX_REBOUNDS;
-                break;
             }
-        }
 
-        // all bounds (ray.py:225-230): any non-zero code stops, the point is not appended
-        if (x_new < e.range_min[0] || x_new > e.range_max[0] || z_new < e.range_min[1] || z_new > e.range_max[1]) {
-            stop = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
-            if (stop) break;
+            // all bounds (ray.py:225-230): any non-zero code stops, the point is not appended
+            if (x_new < e.range_min[0] || x_new > e.range_max[0] || z_new < e.range_min[1] || z_new > e.range_max[1]) {
+                stop = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
+                if (stop) break;
+            }
+            // the sound-speed record prefetched for z_new stands unless a rebound moved the point or the guess was off
+            if (rebound | !okz) rt2d_lookup<7>(tab, e.cz, z_new, rz);
         }
 
         // accept the point (ray.py:235-247)
@@ -392,11 +404,6 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             }
         }
         x = x_new; z = z_new;
-        {
-            // the record prefetched for z_new stands unless a rebound moved the point or the guess was off
-            const bool okz = ((z >= rz[0]) | (jz == 0)) & ((z < rz[7]) | (jz == e.cz.n_pieces - 1)) & (e.cz.uniform != 0) & !rebound;
-            if (!okz) rt2d_lookup<7>(tab, e.cz, z, rz);
-        }
         const double dzr = z - rz[0];
         c = rt2d_quad_of(rz, dzr, 0);
         const double dz_c = rt2d_quad_of(rz, dzr, 1);
