@@ -85,6 +85,8 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     out = _lib.Rt2dRayOut()
     out.n_pts, out.stop_code, out.n_rebounds, out.status = n_pts.data_ptr(), stop.data_ptr(), nreb.data_ptr(), status.data_ptr()
     out.range = rng.data_ptr()
+    mono = torch.empty(n, dtype=torch.uint8, device=device)
+    out.monotone = mono.data_ptr()
     src = (C.c_double * 2)(float(source[0]), float(source[1]))
     p = _lib.Rt2dParams()
     p.dx_max, p.dz_max, p.n_steps_max, p.n_rebounds_max, p.backprop = PROP['dx_max'], PROP['dz_max'], 100000, PROP['n_rebounds_max'], 1
@@ -151,7 +153,12 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         lo, hi = parallel.allreduce_plot_range(lo, hi, device=device)          # C1
     shape = parallel.heatmap_shape(lo, hi, RES)
     H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)
+    # ray_mask with the hint bit: x never decreases (from the cast) and the ray's bounding box is inside the map
     mask = okm.to(torch.uint8)
+    if n > 16384:          # the tile kernel's range (rt2d_heatmap_accumulate); smaller fans use the general kernel
+        inside = ((rng[0] > -1) & (rng[3] < 1) & (torch.div(torch.trunc(rng[2]), RES[0], rounding_mode='floor') < int(shape[0]))
+                  & (torch.div(-torch.trunc(rng[1]), RES[1], rounding_mode='floor') < int(shape[1])))
+        mask = mask * (1 + 2 * (inside & (mono != 0)).to(torch.uint8))
     work = torch.empty(n + 2, **i32)
     res_c = (C.c_int32 * 2)(*RES)
     shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))

@@ -128,6 +128,8 @@ typedef struct {
     double*  margin;       /* smallest distance [m] by which any bound / floor / surface comparison of the loop was
                               decided; a ray with margin ~ 0 is "knife-edge": its step count depends on the last bits
                               of the arithmetic (no counterpart in the reference; used to report parity honestly) */
+    uint8_t* monotone;     /* 1 when no appended point lies left of its predecessor (x never decreases): the hint bit 2
+                              of rt2d_heatmap_accumulate's ray_mask may be set for such a ray */
 } Rt2dRayOut;
 
 const char* rt2d_last_error(void);
@@ -192,6 +194,9 @@ int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, con
  * The cell arithmetic is the reference's integer arithmetic: trunc toward zero, then floor division, then the
  * flat index ix*nz + iz (negative flat indices wrap once, as NumPy indexing does).
  * ray_mask: device, n bytes, nonzero = bin this ray (NULL = all n rays; a RayPack may hold a subset of a fan).
+ *   Bit 2 (value 2) is a HINT the caller may add: "x never decreases along this ray (Rt2dRayOut.monotone) and every
+ *   point of it falls inside the map"; the tile kernel then skips its own check of exactly that.  A wrong hint gives
+ *   a wrong map.
  * G: device, one frequency, tile layout.  res: host, 2 ints (metres per cell in x and z).
  * shape: host, 2 ints (nx, nz).  H: device, nx*nz doubles row-major [ix*nz + iz], accumulated into
  * (caller zeroes it).  n_dropped (device int64, may be NULL, caller zeroes it) counts points whose flat index

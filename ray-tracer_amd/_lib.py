@@ -59,7 +59,7 @@ class Rt2dParams(C.Structure):
 
 RAY_OUT_FIELDS = ['n_pts', 'stop_code', 'n_rebounds', 'status', 'range', 'L_end', 'T_end', 'dist_to_target',
                   'step_target', 'T_target', 'reb_step', 'reb_surface', 'reb_velocity', 'reb_angle', 'reb_pos_x',
-                  'reb_pos_z', 'margin']
+                  'reb_pos_z', 'margin', 'monotone']
 
 
 class Rt2dRayOut(C.Structure):

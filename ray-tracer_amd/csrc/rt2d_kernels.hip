@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     double c_pt = 0.0, L = 0.0, T = 0.0;
     double min_x = x, max_x = x, min_z = z, max_z = z;
     double margin = INFINITY;
+    bool mono = true;
     const bool want_margin = FULL && a.out.margin != nullptr;
     const bool has_target = FULL && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
@@ -367,6 +368,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                     if (POST >= 1) {
                         min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
                         min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
+                        mono &= !(x_new < x);
                     }
                     if (WRITE && n_pts < room) {
                         px += RT2D_WAVE; pz += RT2D_WAVE;
@@ -403,6 +405,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                 g_A += g_pend; g_pend = 0.0;
             }
         }
+        if (POST >= 1) mono &= !(x_new < x);
         x = x_new; z = z_new;
         const double dzr = z - rz[0];
         c = rt2d_quad_of(rz, dzr, 0);
@@ -438,6 +441,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     if (o.status) o.status[r] = status;
     if (POST >= 1) {
         if (o.range) { o.range[r] = min_x; o.range[n + r] = min_z; o.range[2 * n + r] = max_x; o.range[3 * n + r] = max_z; }
+        if (o.monotone) o.monotone[r] = mono ? 1 : 0;
     }
     if (FULL) {
         if (o.L_end) o.L_end[r] = L;
@@ -888,7 +892,9 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     const int64_t n_tiles = (a.n + RT2D_WAVE - 1) / RT2D_WAVE;
     if (tile >= n_tiles) return;
     const int64_t r = tile * RT2D_WAVE + lane;
-    const bool mine = r < a.n && (!a.ray_mask || a.ray_mask[r]);
+    const uint8_t flags = (r < a.n) ? (a.ray_mask ? a.ray_mask[r] : (uint8_t)1) : (uint8_t)0;
+    const bool mine = flags != 0;
+    const bool hinted = (flags & 2) != 0;               // caller vouches for monotone columns and in-map points
     int np = mine ? a.n_pts[r] : 0;
     const int64_t base = a.tile_off[tile] + lane;
     int tmax = np;
@@ -897,7 +903,8 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     // forward check, HM_UNROLL rows in flight per lane
     bool ok = true;
     int64_t prev_ix = INT64_MIN;
-    for (int s0 = 0; s0 < tmax; s0 += HM_UNROLL) {
+    const int t_check = __all(hinted || !mine) ? 0 : tmax;
+    for (int s0 = 0; s0 < t_check; s0 += HM_UNROLL) {
         double xs[HM_UNROLL], zs[HM_UNROLL];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
@@ -916,7 +923,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             }
         }
     }
-    if (!ok) {
+    if (!ok && !hinted) {
         int k = atomicAdd(&a.work[0], 1);
         a.work[2 + k] = (int32_t)r;
         np = 0;
@@ -1235,7 +1242,7 @@ int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out) {
 extern "C++" {
 static int post_level(const Rt2dRayOut& o) {
     if (o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin) return 2;
-    return o.range ? 1 : 0;
+    return (o.range || o.monotone) ? 1 : 0;
 }
 
 template <bool WRITE, int POST, bool CUTOFF>

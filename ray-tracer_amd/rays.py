@@ -13,6 +13,7 @@ Every number comes from the HIP kernels behind include/rt2d.h; there is no CPU f
 """
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -21,6 +22,7 @@ from . import _lib
 from ._lib import STOP_REASONS, RAY_ERR_INTERP
 
 TILE = 64
+HEATMAP_FAST_MIN_RAYS = int(os.environ.get('RT2D_HEATMAP_FAST_MIN_RAYS', 16384))    # same switch as the library's
 SPECULATIVE_ROOM = 4096          # points per ray a speculative single-pass cast reserves
 SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below this
 
@@ -93,6 +95,7 @@ class RayFan:
             self.n_rebounds = torch.empty(n, **i32)
             self.status = torch.empty(n, **i32)
             self.range = torch.empty((4, n), **f64)
+            self.monotone = torch.empty(n, dtype=torch.uint8, device=dev)
             self._scalars = None
             self.dist = torch.full((n,), float('nan'), **f64)
             self.step_target = torch.full((n,), -1, **i32)
@@ -111,6 +114,7 @@ class RayFan:
                 # the bounding box is all the heat-map pipeline needs of the post-pass; L_end / T_end / margin are
                 # produced on demand (_lazy_scalars) so that the main cast does not carry them through every step
                 out.range = self.range.data_ptr()
+                out.monotone = self.monotone.data_ptr()
                 if self.target is not None:
                     out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
                     out.T_target = self.T_target.data_ptr()
@@ -334,7 +338,18 @@ class RayFan:
         return out
 
     # -- heat map (simulation.py:120-131) ---------------------------------------------------------
-    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True):
+    def heatmap_mask(self, res, shape, ray_mask=None):
+        """ray_mask for rt2d_heatmap_accumulate with the hint bit (value 2) set for the rays whose x never decreases and
+        whose bounding box lies inside the map: the tile kernel need not check those point by point."""
+        torch = _torch()
+        rng = self.range
+        inside = ((rng[0] > -1) & (rng[3] < 1)                                  # int(x) >= 0, int(z) <= 0
+                  & (torch.div(torch.trunc(rng[2]), int(res[0]), rounding_mode='floor') < int(shape[0]))
+                  & (torch.div(-torch.trunc(rng[1]), int(res[1]), rounding_mode='floor') < int(shape[1])))
+        base = torch.ones(self.n, dtype=torch.uint8, device=self.device) if ray_mask is None else (ray_mask != 0).to(torch.uint8)
+        return base + 2 * (base * (inside & (self.monotone != 0)).to(torch.uint8))
+
+    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True):
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
         fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests)."""
         self._need_store()
@@ -346,6 +361,8 @@ class RayFan:
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
             work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device) if fast else None
+            if fast and hint and self.n > HEATMAP_FAST_MIN_RAYS:       # smaller fans go through the general kernel anyway
+                ray_mask = self.heatmap_mask(res, shape, ray_mask)
             _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
                                                  self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
                                                  _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),

@@ -89,7 +89,8 @@ class Simulation2D:
             if len(idx) != fan.n:
                 mask = torch.zeros(fan.n, dtype=torch.uint8, device=device)
                 mask[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=device)] = 1
-            fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True))
+            fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True),
+                                   hint=kwargs.get('hint', True))
         return H.view(int(shape[0]), int(shape[1])), dropped
 
     def heatmap(self, **kwargs):

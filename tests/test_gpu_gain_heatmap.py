@@ -118,7 +118,7 @@ def test_gain_vs_oracle_same_points(rt, orc):
     assert worst < 1e-11
 
 
-@pytest.mark.parametrize('fast', [True, False])
+@pytest.mark.parametrize('fast', [True, 'nohint', False])
 @pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
 def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
     """Binning in isolation: oracle heat map over the GPU's own points and gains -> every cell equal to 1e-12.
@@ -128,8 +128,10 @@ def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
     oenv = common.oracle_env_from_product(orc, env)
     sim = rt.Simulation2D(env, g['fan_source'])
     sim.raypacks['main'].add_fan(fan)
-    H, dropped = sim.heatmap_full(resolution=[50, 25], fast=fast)
-    print(f'{name}: fast={fast}: {fan.last_slow_rays} of {fan.n} rays went through the general kernel')
+    hint = fast is True          # 'nohint': tile kernel with its own monotone / in-map check of every ray
+    fast = bool(fast)
+    H, dropped = sim.heatmap_full(resolution=[50, 25], fast=fast, hint=hint)
+    print(f'{name}: fast={fast} hint={hint}: {fan.last_slow_rays} of {fan.n} rays went through the general kernel')
     H = H.cpu().numpy()
     rays = [r for r in _oracle_rays_from_fan(orc, rt, fan) if r.status == 0]
     for r in rays:
@@ -141,7 +143,7 @@ def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
     rel = np.abs(H - Href) / np.maximum(1e-300, np.abs(Href))
     assert rel[Href != 0].max() < 1e-12
     for cutoff in (.02, .1, .5):
-        out = sim.heatmap(resolution=[50, 25], cutoff=cutoff, reduction_power=.5, fast=fast)
+        out = sim.heatmap(resolution=[50, 25], cutoff=cutoff, reduction_power=.5, fast=fast, hint=hint)
         _, plot_ref, _ = orc.heatmap(oenv, rays, res=(50, 25), cutoff=cutoff)
         assert out.shape == plot_ref.shape
         assert np.abs(out - plot_ref).max() < 1e-12
