@@ -174,6 +174,24 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     return total, n_pts, status, outp.view(int(shape[1]), int(shape[0]))
 
 
+def pmc_traffic(large):
+    """HBM bytes per launch of the storing cast from the newest committed PMC profile (profiles/r*/*_traffic.json,
+    written by tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command, with the
+    gfx950 corrections of MI355X_MICROARCH.md).  The 999-ray and the 1M-ray launches differ by grid size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*_traffic.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f)['kernels']
+    cand = [(int(name.split('grid=')[1].split('|')[0]), v) for name, v in k.items()
+            if name.startswith('rt2d_cast_kernel<true') and v.get('hbm_bytes') is not None]
+    if not cand:
+        return None, None
+    cand.sort(key=lambda c: c[0])
+    return (cand[-1] if large else cand[0])[1]['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+
+
 def ray_steps_of(n_pts, status):
     ok = status == 0
     return int((n_pts[ok] - 1).sum().item())
@@ -263,6 +281,7 @@ def main():
         value = steps_all * args.steps / dt
         store_ms = st['cast_store']
         achieved = steps_rank * BYTES_PER_STEP / (store_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(large=False)
         result = {
             'metric': 'ray-steps/sec (node) + s per 999-ray 20-rebound heatmap', 'value': value, 'unit': 'ray-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -273,7 +292,8 @@ def main():
             's_per_heatmap': dt / args.steps,
             'stage_ms': st,
             'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': traffic_src, 'algorithmic_bytes': steps_rank * BYTES_PER_STEP,
                          'note': '999 rays = 16 wavefronts on 256 CUs: latency-bound by construction; see large_fan',
                          'fp64_valu_frac': steps_rank * FLOP_PER_STEP / (store_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
         }
@@ -291,11 +311,13 @@ def main():
         sl = ray_steps_of(n_pts_l, status_l)
         stl = stages_l.summary()
         ach = sl * BYTES_PER_STEP / (stl['cast_store'] * 1e-3) / 1e9
+        traffic_l, traffic_src_l = pmc_traffic(large=True) if nL == (1 << 20) else (None, None)
         result['large_fan'] = {
             'rays': nL, 'ray_steps': sl, 'value': sl * args.large_steps / dtl, 'unit': 'ray-steps/s',
             's_per_heatmap': dtl / args.large_steps, 'stage_ms': stl,
             'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_l,
+                         'traffic_source': traffic_src_l, 'algorithmic_bytes': sl * BYTES_PER_STEP,
                          'fp64_valu_frac': sl * FLOP_PER_STEP / (stl['cast_store'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                          'count_pass_steps_per_s': sl / (stl['cast_count'] * 1e-3)},
         }

@@ -11,6 +11,7 @@ from .physics_environment import PhysicsEnvironment2D  # noqa: F401
 from .environment import Environment2D  # noqa: F401
 from .rays import RayFan, Ray2D, RayPack2D  # noqa: F401
 from .simulation import Simulation2D, EigenraySim2D  # noqa: F401
+from .bathymetry import Map  # noqa: F401
 from . import _lib  # noqa: F401
 
 build = _lib.build

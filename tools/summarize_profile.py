@@ -1,0 +1,92 @@
+"""Turns what tools/profile_gpu.sh left under gpurun_out/prof_TAG/ into the files committed under profiles/.
+
+    python tools/summarize_profile.py TAG [ROUND_DIR]
+
+Writes profiles/ROUND_DIR/TAG_kernel_stats.csv   rocprofv3's own --stats summary (copied as is)
+       profiles/ROUND_DIR/TAG_by_launch.csv      rt2d_* dispatches grouped by (kernel, grid size): the 999-ray fan and the
+                                                 1M-ray fan launch the same kernels, the grid size tells them apart
+       profiles/ROUND_DIR/TAG_traffic.json       HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes, corrected as
+                                                 MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950
+                                                 FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled
+                                                 (calibrated there on wide coalesced streaming reads); WRITE_SIZE is exact
+                                                 for streaming stores and atomics.
+bench.py reads TAG_traffic.json of the newest committed profile for `roofline.traffic`.
+"""
+
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    return re.sub(r'\(.*\)$', '', name)
+
+
+def main():
+    tag = sys.argv[1]
+    rdir = sys.argv[2] if len(sys.argv) > 2 else 'r01'
+    src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
+    dst = os.path.join(ROOT, 'profiles', rdir)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, 'trace', 't_kernel_stats.csv'), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+
+    groups = defaultdict(list)
+    with open(os.path.join(src, 'trace', 't_kernel_trace.csv')) as f:
+        for row in csv.DictReader(f):
+            if 'rt2d_' not in row['Kernel_Name']:
+                continue
+            grid = int(row['Grid_Size_X']) * int(row['Grid_Size_Y']) * int(row['Grid_Size_Z'])
+            key = (short(row['Kernel_Name']), grid, int(row['Workgroup_Size_X']))
+            groups[key].append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
+    pmc = {}
+    for which, sub, fname in (('FETCH_SIZE', 'fetch', 'f_counter_collection.csv'), ('WRITE_SIZE', 'write', 'w_counter_collection.csv')):
+        path = os.path.join(src, sub, fname)
+        acc = defaultdict(list)
+        if os.path.exists(path):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if 'rt2d_' not in row['Kernel_Name'] or row['Counter_Name'] != which:
+                        continue
+                    acc[(short(row['Kernel_Name']), int(row['Grid_Size']), int(row['Workgroup_Size']))].append(float(row['Counter_Value']))
+        pmc[which] = acc
+
+    rows = []
+    traffic = {}
+    for key in sorted(groups, key=lambda k: (k[0], k[1])):
+        d = groups[key]
+        fetch = pmc['FETCH_SIZE'].get(key)
+        write = pmc['WRITE_SIZE'].get(key)
+        fetch_b = None if not fetch else 2 * 1024 * sum(fetch) / len(fetch)          # gfx950 correction: x2
+        write_b = None if not write else 1024 * sum(write) / len(write)
+        rows.append(dict(kernel=key[0], grid_threads=key[1], workgroup=key[2], launches=len(d), avg_ns=sum(d) / len(d),
+                         min_ns=min(d), max_ns=max(d),
+                         hbm_read_bytes='' if fetch_b is None else round(fetch_b),
+                         hbm_write_bytes='' if write_b is None else round(write_b)))
+        traffic[f'{key[0]}|grid={key[1]}|wg={key[2]}'] = dict(
+            avg_ns=sum(d) / len(d), launches=len(d), hbm_read_bytes=fetch_b, hbm_write_bytes=write_b,
+            hbm_bytes=None if fetch_b is None or write_b is None else fetch_b + write_b)
+    with open(os.path.join(dst, f'{tag}_by_launch.csv'), 'w', newline='') as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    with open(os.path.join(dst, f'{tag}_traffic.json'), 'w') as f:
+        json.dump(dict(units='bytes per launch; FETCH_SIZE [KiB] x 1024 x 2 (gfx950), WRITE_SIZE [KiB] x 1024',
+                       kernels=traffic), f, indent=1)
+    for line in open(os.path.join(src, 'trace.log')):
+        if line.startswith('{'):
+            with open(os.path.join(dst, f'{tag}_bench.json'), 'w') as f:
+                f.write(line)
+    for r in rows:
+        print(f"{r['kernel'][:60]:60s} grid {r['grid_threads']:>9d} x{r['launches']:<3d} avg {r['avg_ns'] / 1e3:10.1f} us  "
+              f"rd {r['hbm_read_bytes'] or 0:>12} wr {r['hbm_write_bytes'] or 0:>12}")
+
+
+if __name__ == '__main__':
+    main()
