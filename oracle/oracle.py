@@ -86,6 +86,8 @@ def lib():
         _lib.orc_run_fan.restype = C.c_int64
         _lib.orc_run_fan.argtypes = [C.POINTER(OrcEnv), dp, dp, C.c_int64, C.POINTER(OrcParams), C.c_double,
                                      C.c_double, C.c_double, ip, ip, dp, dp, C.POINTER(C.c_int64)]
+        _lib.orc_check_div_by_const.restype = C.c_int64
+        _lib.orc_check_div_by_const.argtypes = [C.c_double, C.c_int64, C.c_uint64]
         _lib.orc_absorption.restype = C.c_double
         _lib.orc_absorption.argtypes = [C.POINTER(OrcEnv), C.c_double, C.c_double]
     return _lib

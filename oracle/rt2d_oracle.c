@@ -386,3 +386,28 @@ int64_t orc_run_fan(const OrcEnv* env, const double* src, const double* angles, 
     free(rs); free(rsurf); free(rv); free(ra); free(rpx); free(rpz);
     return steps;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Checker for an identity the HIP stepping kernel relies on (rt2d_div_by_const, csrc/rt2d_kernels.hip): for b > 0 and
+ * y = RN(1/b), two FMA correction steps on q0 = a*y give the IEEE quotient a/b bit for bit.  Returns the number of
+ * samples (n random a spread over 2^-200 .. 2^200, both signs) on which the two differ: must be 0. */
+int64_t orc_check_div_by_const(double b, int64_t n, uint64_t seed) {
+    const double y = 1.0 / b;
+    uint64_t s = seed ? seed : 88172645463325252ull;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const uint64_t m = s;
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const int e = (int)(s % 400) - 200;
+        double a = ldexp((double)(m >> 11) * 0x1p-53 + 0.5, e);
+        if (m & 1) a = -a;
+        const double q0 = a * y;
+        const double r0 = fma(-q0, b, a);
+        const double q1 = fma(r0, y, q0);
+        const double r1 = fma(-q1, b, a);
+        const double q2 = fma(r1, y, q1);
+        bad += (q2 != a / b);
+    }
+    return bad;
+}

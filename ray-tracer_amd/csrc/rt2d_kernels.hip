@@ -42,6 +42,8 @@ struct rt2d_env_s {
     double* blob;       // device
     int device;
     int n_cu;           // compute units of that device
+    bool ceil_is_const; // the surface table is one constant (slopes 0, equal values) ...
+    double ceil_const;  // ... this one
     std::vector<double> host_blob;
 };
 
@@ -60,8 +62,23 @@ struct CastArgs {
     const int64_t* tile_off;
     double* X; double* Z; double* C;
     double g_cut;                 // power cut-off in dB, 10*log10(power_cutoff); only read by the CUTOFF kernels
+    double inv_dx_max;            // RN(1 / dx_max), for rt2d_div_by_const
+    double ceil_const;            // the surface depth when the surface table is constant (CEILC kernels)
     int32_t lanes;                // rays per wave (1..64, power of two): small fans are spread over more waves
 };
+
+// RN(a / b) for a divisor b > 0 whose correctly rounded reciprocal y = RN(1/b) is known (Markstein's correction
+// steps, each one FMA): q1 is a faithful quotient, and q1 + (a - b*q1)*y then rounds to the IEEE quotient, so the
+// result is the one `a / b` gives, bit for bit, at 5 instructions instead of the 13 of the general fp64 division.
+// Valid away from overflow / underflow of the residuals (callers check |a|); tests/test_oracle.py::test_div_by_const
+// checks the identity on the host, the cast parity tests check it on the device.
+__device__ __forceinline__ double rt2d_div_by_const(double a, double b, double y) {
+    double q0 = a * y;
+    double r0 = fma(-q0, b, a);
+    double q1 = fma(r0, y, q0);
+    double r1 = fma(-q1, b, a);
+    return fma(r1, y, q1);
+}
 
 __device__ __forceinline__ double rt2d_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
 
@@ -187,7 +204,10 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 // p.cutoff_freq is carried along (S = absorption cumsum, A = rebound losses, exactly the gain kernel's expressions)
 // and the ray ends with the first point whose G = S + A is below the cut-off; that point is kept.  The gain tables
 // are read from global memory here (they sit behind the step section of the blob).
-template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF>
+// CEILC: the surface table is one constant (the sea surface z = 0 of every configuration of the reference): its lookup,
+// the verification of its guess and its interpolation drop out of the step; the value is the same bit for bit
+// (slope 0: 0 * d + c == c).
+template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC>
 __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
@@ -260,26 +280,58 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     const double* gtab = a.blob + e.gain_off;
     if (CUTOFF) { double f = p.cutoff_freq / 1000; g_ff = f * f; }
 
+    // fmin / fmax through the bare instructions: in IEEE mode the compiler quiets every operand it cannot prove canonical
+    // with an extra v_max_f64 x, x in front of each fmin / fmax, and the proof does not reach loop-invariant values across
+    // the loop boundary -- five extra instructions per step.  v_max_f64 / v_min_f64 themselves return the non-NaN
+    // operand and quiet a NaN result, which is what fmax / fmin do.
+    auto vmax = [](double u, double v) -> double { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v)); return r; };
+    auto vmin = [](double u, double v) -> double { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v)); return r; };
+    const double fl_jmax = (double)(e.floor.n_pieces - 1), ce_jmax = (double)(e.ceil.n_pieces - 1);
+    const double cz_jmax = (double)(e.cz.n_pieces - 1);
+    // the bounds those instructions take, parked in vector registers for the whole loop (the empty asm keeps the compiler
+    // from re-creating them from scalar registers in front of every use)
+    double fl_lo = e.floor.lo, fl_hi = e.floor.hi, ce_lo = e.ceil.lo, ce_hi = e.ceil.hi;
+    double z_lo_bound = e.range_min[1], z_hi_bound = e.range_max[1];
+    if (CEILC) z_hi_bound = vmin(z_hi_bound, a.ceil_const);
+    asm volatile("" : "+v"(fl_lo), "+v"(fl_hi), "+v"(z_lo_bound), "+v"(z_hi_bound));
+    if (!CEILC) asm volatile("" : "+v"(ce_lo), "+v"(ce_hi));
+    auto guess = [&](const DevTable& t, double v, double jmax) -> int {     // rt2d_guess
+        double g = (v - t.x0) * t.inv_h;
+        return (int)vmin(vmax(g, 0.0), jmax);                               // NaN -> 0 through the max
+    };
+
     for (int i = 0; i < p.n_steps_max; ++i) {
         // step sizing (ray.py:153-154)
-        if (fabs(dx_z) > dx_z_max) { double s = p.dz_max / fabs(dx_z); kx *= s; kz *= s; }
-        else { kx *= p.dx_max; kz *= p.dx_max; }
+        const bool steep = fabs(dx_z) > dx_z_max;
+        {
+            double s = p.dx_max;
+            if (__any(steep)) {                  // wave-uniform: a wave of shallow rays never pays for the division
+                const double ss = p.dz_max / fabs(dx_z);
+                if (steep) s = ss;
+            }
+            kx *= s; kz *= s;
+        }
         double x_new = x + kx, z_new = z + kz;                            // ray.py:157
 
         // The three table records the common step needs -- floor and ceiling under x_new (ray.py:172-173; both tables
         // clamp, checked by rt2d_env_create) and c, dc/dz at z_new (ray.py:237-238) -- are fetched in ONE batch of
         // independent LDS reads from guessed pieces.  The guesses are verified below; the sound-speed record is only
         // used if the point is accepted as it stands (a rebound moves it, and then the lookup is redone).
-        const double xa = fmin(fmax(x_new, e.floor.lo), e.floor.hi), xb = fmin(fmax(x_new, e.ceil.lo), e.ceil.hi);
-        int ja = rt2d_guess(e.floor, xa), jb = rt2d_guess(e.ceil, xb);
-        const int jz = rt2d_guess(e.cz, z_new);
+        const double xa = vmin(vmax(x_new, fl_lo), fl_hi);
+        const double xb = CEILC ? 0.0 : vmin(vmax(x_new, ce_lo), ce_hi);
+        int ja = guess(e.floor, xa, fl_jmax), jb = CEILC ? 0 : guess(e.ceil, xb, ce_jmax);
+        const int jz = guess(e.cz, z_new, cz_jmax);
         double ra[4], rb[4], rz[8];
         {
             auto pa = tab + e.floor.off + ja * 3;
-            auto pb = tab + e.ceil.off + jb * 3;
             auto pzr = tab + e.cz.off + jz * 7;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { ra[k] = pa[k]; rb[k] = pb[k]; }
+            for (int k = 0; k < 4; ++k) ra[k] = pa[k];
+            if (!CEILC) {
+                auto pb = tab + e.ceil.off + jb * 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rb[k] = pb[k];
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) rz[k] = pzr[k];
         }
@@ -287,12 +339,12 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         // recognised by ONE predicate and skips every branch of the general case below; when the predicate fails the
         // general case runs in the reference's order (ray.py:162-230) and none of its branches would fire otherwise.
         const bool oka = ((xa >= ra[0]) | (ja == 0)) & ((xa < ra[3]) | (ja == e.floor.n_pieces - 1)) & (e.floor.uniform != 0);
-        const bool okb = ((xb >= rb[0]) | (jb == 0)) & ((xb < rb[3]) | (jb == e.ceil.n_pieces - 1)) & (e.ceil.uniform != 0);
+        const bool okb = CEILC ? true : (((xb >= rb[0]) | (jb == 0)) & ((xb < rb[3]) | (jb == e.ceil.n_pieces - 1)) & (e.ceil.uniform != 0));
         const bool okz = ((z_new >= rz[0]) | (jz == 0)) & ((z_new < rz[7]) | (jz == e.cz.n_pieces - 1)) & (e.cz.uniform != 0);
         double z_floor = ra[1] * (xa - ra[0]) + ra[2];
-        double z_ceil = rb[1] * (xb - rb[0]) + rb[2];
+        double z_ceil = CEILC ? a.ceil_const : rb[1] * (xb - rb[0]) + rb[2];
         const bool general = !(oka & okb & okz) | (x_new < e.range_min[0]) | (x_new > e.range_max[0])
-                           | (z_new < e.range_min[1]) | (z_new > e.range_max[1]) | (z_new < z_floor) | (z_new > z_ceil);
+                           | (z_new < vmax(z_lo_bound, z_floor)) | (z_new > (CEILC ? z_hi_bound : vmin(z_hi_bound, z_ceil)));
         if (want_margin && !general) {
             margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
@@ -307,13 +359,17 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             }
             if (!(oka & okb)) {
                 ja = rt2d_fix_piece(tab, e.floor, xa, ja);
-                jb = rt2d_fix_piece(tab, e.ceil, xb, jb);
                 auto pa = tab + e.floor.off + ja * 3;
-                auto pb = tab + e.ceil.off + jb * 3;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { ra[k] = pa[k]; rb[k] = pb[k]; }
+                for (int k = 0; k < 3; ++k) ra[k] = pa[k];
                 z_floor = ra[1] * (xa - ra[0]) + ra[2];
-                z_ceil = rb[1] * (xb - rb[0]) + rb[2];
+                if (!CEILC) {
+                    jb = rt2d_fix_piece(tab, e.ceil, xb, jb);
+                    auto pb = tab + e.ceil.off + jb * 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rb[k] = pb[k];
+                    z_ceil = rb[1] * (xb - rb[0]) + rb[2];
+                }
             }
             if (want_margin) margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
 
@@ -322,7 +378,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             const bool rebound = hit_floor || hit_ceil;
             if (rebound) {                                                    // ray.py:176-220
                 const DevTable slope_t = hit_floor ? cold->dx_floor : cold->dx_ceil;
-                double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : rt2d_eval_lin(tab, e.ceil, x);
+                double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : (CEILC ? a.ceil_const : rt2d_eval_lin(tab, e.ceil, x));
                 x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
                 z_new = hit_floor ? z_floor : z_ceil;
                 bool ok;
@@ -424,7 +480,15 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         n_pts += 1;
         if (CUTOFF && cut) { stop = RT2D_STOP_POWER_CUTOFF; break; }
         x_dir = rt2d_sign(kx);
-        dx_z = kz / kx;
+        // k1/k0 (ray.py:243).  In a wave whose rays all took a plain dx_max step, k0 is +-dx_max exactly and the quotient
+        // comes from rt2d_div_by_const (same bits); any other wave divides.
+        const bool plain = !steep & !general & (fabs(kx) == p.dx_max) & (fabs(kz) >= 1e-250);
+        if (__all(plain)) {
+            const double q = rt2d_div_by_const(kz, p.dx_max, a.inv_dx_max);
+            dx_z = (kx < 0.0) ? -1 * q : q;
+        } else {
+            dx_z = kz / kx;
+        }
         double dxdx_z = mult * dz_c / (c * c * c);
         dx_z += dxdx_z * kx;
         kx = x_dir; kz = dx_z;
@@ -1214,6 +1278,11 @@ int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
     e.gain_doubles = (int32_t)blob.size() - e.gain_off;
     e.total_doubles = (int32_t)blob.size();
     e.c_surface = host_eval_quad0(blob, e.cz, 0.0);
+    env->ceil_is_const = true;
+    env->ceil_const = d->ceil.coef[1] + 0.0;                 // -0 -> +0
+    for (int j = 0; j < d->ceil.n_pieces; ++j)
+        if (d->ceil.coef[2 * j] != 0.0 || d->ceil.coef[2 * j + 1] != env->ceil_const) env->ceil_is_const = false;
+    if (getenv("RT2D_NO_CEILC")) env->ceil_is_const = false;   // tests compare both kernels
     if (hipGetDevice(&env->device) != hipSuccess) { delete env; return fail("no HIP device available"); }
     if (hipDeviceGetAttribute(&env->n_cu, hipDeviceAttributeMultiprocessorCount, env->device) != hipSuccess || env->n_cu <= 0) env->n_cu = 256;
     if (hipMalloc(&env->blob, blob.size() * sizeof(double)) != hipSuccess) { delete env; return fail("hipMalloc of the table blob failed"); }
@@ -1278,11 +1347,12 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     const int64_t grid = (n + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     if (in_lds) {
-        auto k = rt2d_cast_kernel<WRITE, true, POST, CUTOFF>;
+        auto k = env->ceil_is_const ? rt2d_cast_kernel<WRITE, true, POST, CUTOFF, true> : rt2d_cast_kernel<WRITE, true, POST, CUTOFF, false>;
+        a.ceil_const = env->ceil_const;
         HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST, CUTOFF>), dim3((unsigned)grid), dim3(block), lds, stream, a);
+        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST, CUTOFF, false>), dim3((unsigned)grid), dim3(block), lds, stream, a);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -1321,6 +1391,7 @@ static CastArgs make_cast_args(rt2d_env_t env, const double* angles, int64_t n, 
     a.env = env->dev; a.blob = env->blob; a.angles = angles; a.init_slope = init_slope; a.init_mult = init_mult;
     a.n = n; a.src_x = src[0]; a.src_z = src[1]; a.p = *p; a.out = *out;
     a.g_cut = p->power_cutoff > 0 ? 10 * log10(p->power_cutoff) : -INFINITY;
+    a.inv_dx_max = 1.0 / p->dx_max;
     return a;
 }
 
