@@ -235,11 +235,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # one rank per GPU; wraps only when rehearsed on fewer GPUs
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('RT2D_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; gloo only to rehearse on one GPU
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import rt2d_loader
     rt = rt2d_loader.load()
@@ -268,8 +273,9 @@ def main():
     steps_rank = ray_steps_of(n_pts, status)
     t = torch.tensor([dt, float(steps_rank)], dtype=torch.float64, device=device)
     if world > 1:
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        from ray_tracer_amd import parallel
+        tmax = parallel._all_reduce(t.clone(), dist.ReduceOp.MAX)
+        tsum = parallel._all_reduce(t.clone(), dist.ReduceOp.SUM)
         dt, steps_all = float(tmax[0].item()), float(tsum[1].item())
     else:
         steps_all = float(steps_rank)

@@ -26,6 +26,24 @@ def world():
     return 0, 1
 
 
+def _all_reduce(t, op):
+    """dist.all_reduce that also works for device tensors under a CPU-only backend (gloo: staged through the host)."""
+    dist = _dist()
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def active():
+    """True inside an initialised process group of more than one rank."""
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def shard_angles(angles, rank=None, world_size=None, mode='interleave'):
     """This rank's share of a fan.
 
@@ -56,7 +74,7 @@ def allreduce_plot_range(range_min_plot, range_max_plot, device=None):
         return lo.copy(), hi.copy()
     # one collective: max over (-min, max)
     t = torch.tensor(np.concatenate((-lo, hi)), dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     t = t.cpu().numpy()
     return -t[:2], t[2:]
 
@@ -71,7 +89,7 @@ def allreduce_heatmap(H):
     """C2: sum the per-rank heat maps in place (a torch tensor on this rank's device)."""
     dist = _dist()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(H, op=dist.ReduceOp.SUM)
+        _all_reduce(H, dist.ReduceOp.SUM)
     return H
 
 
@@ -89,9 +107,12 @@ def allgather_topk(dist_local, angles_local, k):
     cand[0, :kk] = best.values
     cand[1, :kk] = a[best.indices]
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = cand.device
+        if cand.is_cuda and dist.get_backend() == 'gloo':
+            cand = cand.cpu()
         parts = [torch.empty_like(cand) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, cand)
-        cand = torch.cat(parts, dim=1)
+        cand = torch.cat(parts, dim=1).to(dev)
     order = torch.argsort(cand[0], stable=True)[:k]
     out_d, out_a = cand[0, order], cand[1, order]
     keep = torch.isfinite(out_d)

@@ -13,6 +13,7 @@ import numpy as np
 
 from .rays import RayFan, RayPack2D, _torch
 from . import _lib
+from . import parallel
 
 
 class Simulation2D:
@@ -23,7 +24,13 @@ class Simulation2D:
         :param source: source point (x, z)
         :param kwargs/pack_default: default pack name ('main'; None = create packs by hand)
         :param kwargs/verbose, verbose_depth, verbose_depth_max: accepted as in the reference
+        :param kwargs/distributed: (build-specific) one process per GPU under torch.distributed: ``cast`` keeps this
+            rank's share of every fan (``shard='interleave'|'block'``, parallel.shard_angles) and ``heatmap`` combines
+            the ranks with the two all-reduces of parallel.py (plot range, then the map); every rank returns the
+            whole map.  Without an initialised process group it changes nothing.
         """
+        self.distributed = bool(kwargs.get('distributed', False))
+        self.shard = kwargs.get('shard', 'interleave')
         self.verbose = kwargs.get('verbose', False)
         self.verbose_depth_max = kwargs.get('verbose_depth_max', 0)
         self.verbose_depth = kwargs.get('verbose_depth', 0)
@@ -62,6 +69,9 @@ class Simulation2D:
         if len(angles) == 1 and np.ndim(angles[0]) == 1:
             angles = angles[0]
         angles = np.asarray(angles, dtype=np.float64)
+        if self.distributed and parallel.active():
+            angles, _ = parallel.shard_angles(angles, mode=kwargs.get('shard', self.shard))
+            raypack.sharded = True            # this pack holds one rank's share: heatmap() combines the ranks
         fan = RayFan(self.env, self.source, angles, target=kwargs.get('target', None), store=kwargs.get('store', True),
                      **{k: kwargs[k] for k in RayFan.PROPAGATE_DEFAULTS if k in kwargs})
         if kwargs.get('strict', False) and bool((fan.status == _lib.RAY_ERR_INTERP).any().item()):
@@ -79,9 +89,14 @@ class Simulation2D:
             res = res.astype(np.int64)
         freq = kwargs.get('freq', 1)
         raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
-        shape = np.ceil(raypack.size_plot / res).astype(int) + 1         # simulation.py:117
         segs = raypack.segments()
         device = segs[0][0].device if segs else torch.device('cuda', torch.cuda.current_device())
+        dist_on = getattr(raypack, 'sharded', False) and parallel.active()
+        if dist_on:                                                       # C1: the plot range of ALL ranks' rays
+            lo, hi = parallel.allreduce_plot_range(raypack.range_min_plot, raypack.range_max_plot, device=device)
+            shape = parallel.heatmap_shape(lo, hi, res)
+        else:
+            shape = np.ceil(raypack.size_plot / res).astype(int) + 1     # simulation.py:117
         H = torch.zeros(int(shape[0]) * int(shape[1]), dtype=torch.float64, device=device)
         dropped = torch.zeros(1, dtype=torch.int64, device=device)
         for fan, idx in segs:
@@ -91,6 +106,9 @@ class Simulation2D:
                 mask[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=device)] = 1
             fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True),
                                    hint=kwargs.get('hint', True))
+        if dist_on:                                                       # C2: sum of the ranks' maps
+            parallel.allreduce_heatmap(H)
+            parallel._all_reduce(dropped, parallel._dist().ReduceOp.SUM)
         return H.view(int(shape[0]), int(shape[1])), dropped
 
     def heatmap(self, **kwargs):
@@ -175,20 +193,31 @@ class EigenraySim2D(Simulation2D):
         kw = self._prop()
         kw['n_rebounds_max'] = self.n_rebounds_max
         torch = _torch()
+        dist_on = self.distributed and parallel.active()
+        if dist_on:
+            angles, _ = parallel.shard_angles(angles, mode=self.shard)
         sweep = RayFan(self.env, self.source, angles, target=self.target, store=False, **kw)
         self.scan_fan = sweep
         # keep the rays whose distance is among the n_rays smallest distinct distances (simulation.py:241-249):
         # top-k on the device, ties kept
         dist = sweep.dist.clone()
         dist[sweep.status != 0] = float('nan')
-        valid = ~torch.isnan(dist)
-        uniq = torch.unique(dist[valid])                       # sorted ascending
-        if uniq.numel() == 0:
-            raise KeyError('no scanning ray reaches the target abscissa')
-        kth = uniq[min(self.n_rays, uniq.numel()) - 1]
-        sel = torch.nonzero(valid & (dist <= kth)).flatten()
-        sel = sel[torch.argsort(dist[sel], stable=True)]
-        sel_angles = angles[sel.cpu().numpy()]
+        if dist_on:
+            # C3: every rank contributes its n_rays best rays, the merged list is the same on every rank (ties beyond a
+            # rank's n_rays-th ray are not kept, unlike the single-process rule below)
+            best_d, best_a = parallel.allgather_topk(dist, sweep.angles_dev, self.n_rays)
+            if best_d.numel() == 0:
+                raise KeyError('no scanning ray reaches the target abscissa')
+            sel_angles = best_a.cpu().numpy()
+        else:
+            valid = ~torch.isnan(dist)
+            uniq = torch.unique(dist[valid])                       # sorted ascending
+            if uniq.numel() == 0:
+                raise KeyError('no scanning ray reaches the target abscissa')
+            kth = uniq[min(self.n_rays, uniq.numel()) - 1]
+            sel = torch.nonzero(valid & (dist <= kth)).flatten()
+            sel = sel[torch.argsort(dist[sel], stable=True)]
+            sel_angles = angles[sel.cpu().numpy()]
         # re-cast the selected rays with trajectories so they are full Ray2D objects
         self.raypacks[self.pack_scan] = RayPack2D()
         fan = RayFan(self.env, self.source, sel_angles, target=self.target, store=True, **kw)
