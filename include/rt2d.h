@@ -130,6 +130,8 @@ typedef struct {
                               of the arithmetic (no counterpart in the reference; used to report parity honestly) */
     uint8_t* monotone;     /* 1 when no appended point lies left of its predecessor (x never decreases): the hint bit 2
                               of rt2d_heatmap_accumulate's ray_mask may be set for such a ray */
+    double*  slope_max;    /* largest |dz/dx| of any step of the ray: bounds the rows a ray can visit inside one heat-map
+                              column (rt2d_cast_heatmap's precondition) */
 } Rt2dRayOut;
 
 const char* rt2d_last_error(void);
@@ -163,6 +165,27 @@ int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const d
                         const Rt2dParams* params, const double* init_slope, const double* init_mult,
                         const Rt2dRayOut* out, const int64_t* tile_off, double* X, double* Z, double* C,
                         void* stream);
+
+/* Fused cast -> gain at one frequency -> heat-map accumulation: the rays are propagated, their gain (rt2d_gain's
+ * expressions, same bits) is carried along and every point is binned into H as it is produced; no trajectory is
+ * written to HBM (16 + 8 B per ray-step saved twice over).  Takes over, for the rays it is given, the sequence
+ * Ray2D.propagate (ray.py:70-289) -> populate_NEW (ray.py:339-369) -> heat-map assignment and sum
+ * (simulation.py:120-131, functions.py:12-19); the reference itself has no such fused form.
+ * Precondition per ray (the caller selects with ray_mask, n bytes, 0 = skip the ray, NULL = all): no ray error, x never
+ * decreases (Rt2dRayOut.monotone), every point inside the map (Rt2dRayOut.range against shape), and at most 8 rows
+ * visited inside one column: floor(res_x * slope_max / res_z) + 2 <= 8 -- all known from a prior rt2d_cast_count.  "Last
+ * write wins" is then local to the column a ray is in.  The other rays go through rt2d_cast_write + rt2d_gain +
+ * rt2d_heatmap_accumulate into the same H.
+ * sign multiplies every deposited value (1.0 normally).  out: only n_pts, stop_code, n_rebounds, status, range,
+ * monotone, slope_max (may be NULL).  irregular (device, n bytes, may be NULL) / n_violations (device int64, may be
+ * NULL, caller zeroes it): a ray that breaks the precondition stops being binned, is flagged and counted -- with a
+ * ray_mask built as above the count is 0; otherwise H is not the reference's map.
+ * Fails (<0) when the sound-speed, floor, surface and absorption tables do not fit in LDS together. */
+int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const double* src,
+                          const Rt2dParams* params, const double* init_slope, const double* init_mult,
+                          const uint8_t* ray_mask, double freq, const int32_t* res, const int32_t* shape,
+                          double sign, double* H, const Rt2dRayOut* out, uint8_t* irregular,
+                          int64_t* n_violations, void* stream);
 
 /* Copies trajectories from one tile layout to another (typically provisional -> exact); the first
  * tile_off_dst[t+1]-tile_off_dst[t] elements of every tile are copied.  C_src/C_dst may both be NULL.

@@ -48,6 +48,79 @@ struct rt2d_env_s {
 };
 
 // ------------------------------------------------------------------------------------------------------
+// heat-map cell arithmetic and deposit (shared by the fused stepping kernel and the heat-map kernels)
+__device__ __forceinline__ int64_t rt2d_floordiv(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+
+// Cell indices of a point: ix = int(x) // res_x, iz = int(z) // (-res_z) (simulation.py:123-125: C truncation, then
+// Python floor division).  64-bit integer division costs ~150 instructions on this hardware and there are two per
+// point, so coordinates below 2^31 take a reciprocal multiply with an exact remainder fix-up instead: t and b are
+// integers, fma(-q, b, t) is exact, and q = floor(t * (1/b)) can only be one off when t/b is an integer.
+struct HeatGeom { int32_t res_x, res_z; double rx, rz, inv_rx, inv_rz, lim; };     // lim: |coordinate| bound of the fast division
+
+__device__ __forceinline__ int64_t rt2d_fdiv_pos(double t, double b, double inv_b) {     // floor(t / b), b > 0
+    double q = floor(t * inv_b);
+    double rem = fma(-q, b, t);
+    if (rem < 0.0) q -= 1.0; else if (rem >= b) q += 1.0;
+    return (int64_t)(int32_t)q;
+}
+
+__device__ __forceinline__ void rt2d_cell_xz(const HeatGeom& g, double x, double z, int64_t& ix, int64_t& iz) {
+    if (fabs(x) < g.lim && fabs(z) < g.lim) {
+        ix = rt2d_fdiv_pos(trunc(x), g.rx, g.inv_rx);
+        iz = rt2d_fdiv_pos(-trunc(z), g.rz, g.inv_rz);          // a // (-b) == (-a) // b
+    } else {
+        ix = rt2d_floordiv((int64_t)x, g.res_x);
+        iz = rt2d_floordiv((int64_t)z, -1 * (int64_t)g.res_z);
+    }
+}
+
+// flat cell index of a point, or -1 when it falls outside the map (functions.py:16; one negative wrap as NumPy does)
+__device__ __forceinline__ int64_t rt2d_cell(const HeatGeom& g, double x, double z, int64_t nz, int64_t size) {
+    int64_t ix, iz;
+    rt2d_cell_xz(g, x, z, ix, iz);
+    int64_t flat = ix * nz + iz;
+    if (flat < 0) flat += size;
+    if (flat < 0 || flat >= size) return -1;
+    return flat;
+}
+
+// vals = (10**(G/10))**-0.1 (ray.py:317, simulation.py:129).  While 10**(G/10) is a normal double this is 10**(-G/100)
+// to ~1e-15 relative (the heat-map tolerance is 1e-12) and one exp2 replaces two pows; outside that range the two
+// pows are evaluated as written so that underflow to 0 -> inf behaves as in the reference.
+__device__ __forceinline__ double rt2d_heat_val(double g) {
+    if (g > -3000.0 && g < 3000.0) return exp2(g * -0.033219280948873623);     // -log2(10)/100
+    double tmult = pow(10.0, g / 10);
+    return pow(tmult, -0.1);
+}
+
+
+// Adds val into H[cell] for every lane that calls with want = true.  Neighbouring lanes are neighbouring angles and
+// mostly sit in the same cell at the same step: runs of adjacent depositing lanes with equal cells are summed first
+// (segmented inclusive scan) and the last lane of each run issues ONE atomic.  Callable from divergent code: only the
+// lanes that call take part, and nothing is read from a lane outside the caller's own run.
+__device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, double val, int lane) {
+    const unsigned long long act = __ballot(want);
+    if (act == 0) return;
+    const int c_prev = __shfl_up(cell, 1);
+    const bool prev_in = lane > 0 && ((act >> (lane - 1)) & 1ull);
+    const bool head = want && !(prev_in && c_prev == cell);
+    const unsigned long long heads = __ballot(head);
+    const int head_pos = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));    // head of this lane's run
+    double v = want ? val : 0.0;
+#pragma unroll
+    for (int off = 1; off < RT2D_WAVE; off <<= 1) {
+        const double v_up = __shfl_up(v, off);
+        if (want && lane - off >= head_pos) v += v_up;
+    }
+    const bool tail = want && (lane == RT2D_WAVE - 1 || !((act >> (lane + 1)) & 1ull) || ((heads >> (lane + 1)) & 1ull));
+    if (tail) atomicAdd(&H[cell], v);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // stepping
 struct CastArgs {
     DevEnv env;
@@ -65,6 +138,14 @@ struct CastArgs {
     double inv_dx_max;            // RN(1 / dx_max), for rt2d_div_by_const
     double ceil_const;            // the surface depth when the surface table is constant (CEILC kernels)
     int32_t lanes;                // rays per wave (1..64, power of two): small fans are spread over more waves
+    // fused cast -> gain -> heat map (FUSE kernels)
+    const uint8_t* ray_mask;      // n bytes, 0 = leave this ray out
+    double* H; HeatGeom geo; int32_t nx, nz;
+    double heat_freq, sign;
+    uint8_t* irregular;           // n bytes (may be NULL): 1 = the ray broke a precondition of the fused binning
+    unsigned long long* n_violations;
+    int32_t fuse_step_doubles;    // blob prefix staged in LDS: sound speed, floor, surface (slopes are read from global)
+    int32_t fuse_abs_doubles;     // length of the absorption table staged behind it
 };
 
 // RN(a / b) for a divisor b > 0 whose correctly rounded reciprocal y = RN(1/b) is known (Markstein's correction
@@ -207,8 +288,15 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 // CEILC: the surface table is one constant (the sea surface z = 0 of every configuration of the reference): its lookup,
 // the verification of its guess and its interpolation drop out of the step; the value is the same bit for bit
 // (slope 0: 0 * d + c == c).
-template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC>
-__global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
+// FUSE: no trajectory leaves the kernel: the gain at a.heat_freq is carried along (as under CUTOFF, but with the
+// absorption table in LDS) and every point is binned into the heat map H on the fly.  Only for rays whose columns never
+// decrease, whose points all fall inside the map and that visit at most 8 rows per column (the caller's ray_mask,
+// RayFan.fused_mask): then "last write wins" (functions.py:16) is local to the column a ray is in -- a register entry for
+// the row it is in, 8 LDS slots per lane for rows it has left but may come back to -- and the column is deposited when
+// the ray leaves it.  Slope tables and the impedance table are read from global memory (rebounds only) to make room.
+#define RT2D_FUSE_MAX_WAVES 12      // launch bound of the FUSE kernels: 3 waves per SIMD leave them 168 vector registers
+template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC, bool FUSE = false>
+__global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
     CastCold* cold = reinterpret_cast<CastCold*>(s_mem);
@@ -218,12 +306,19 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         cold->rebound_cap = a.p.rebound_cap; cold->n_rebounds_max = a.p.n_rebounds_max;
     }
     const double* tab;
+    const int n_stage = FUSE ? a.fuse_step_doubles : a.env.step_doubles;
     if (LDS_TABLES) {
-        for (int i = threadIdx.x; i < a.env.step_doubles; i += blockDim.x) s_tab[i] = a.blob[i];
+        for (int i = threadIdx.x; i < n_stage; i += blockDim.x) s_tab[i] = a.blob[i];
         tab = s_tab;
     } else {
         tab = a.blob;
     }
+    double* s_abs = s_tab + n_stage;                       // FUSE: absorption table, then 8 x 64 slots per wave
+    if (FUSE) {
+        const double* src_abs = a.blob + a.env.gain_off + a.env.absorb.off;
+        for (int i = threadIdx.x; i < a.fuse_abs_doubles; i += blockDim.x) s_abs[i] = src_abs[i];
+    }
+    const double* tab_slope = FUSE ? a.blob : tab;         // where the slope tables are read from
     __syncthreads();
     // Ray of this lane.  A wave executes the rebound branch whenever ANY of its lanes rebounds, which with 64 rays is
     // most steps; a small fan therefore uses only `lanes` lanes of each wave and spreads over up to one wave per CU
@@ -232,6 +327,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     if (lane >= a.lanes) return;
     const int64_t r = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * a.lanes + lane;
     if (r >= a.n) return;
+    if (FUSE && a.ray_mask && !a.ray_mask[r]) return;
     const DevEnv& e = a.env;
     const Rt2dParams& p = a.p;
 
@@ -268,6 +364,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     double min_x = x, max_x = x, min_z = z, max_z = z;
     double margin = INFINITY;
     bool mono = true;
+    double slope_max = 0.0;
     const bool want_margin = FULL && a.out.margin != nullptr;
     const bool has_target = FULL && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
@@ -278,7 +375,56 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     // running gain at the cut-off frequency
     double g_S = 0.0, g_A = 0.0, g_pend = 0.0, g_ff = 0.0;
     const double* gtab = a.blob + e.gain_off;
-    if (CUTOFF) { double f = p.cutoff_freq / 1000; g_ff = f * f; }
+    const double g_freq = FUSE ? a.heat_freq : p.cutoff_freq;
+    if (CUTOFF || FUSE) { double f = g_freq / 1000; g_ff = f * f; }
+    DevTable ab_lds = e.absorb; ab_lds.off = 0;            // the LDS copy of the absorption table starts at s_abs
+
+    // ---- fused binning state (FUSE) ----
+    int cur_ix = INT32_MIN, cur_iz = 0, col_lo = 0, col_hi = 0;
+    unsigned occ = 0;                                      // slots of the current column that hold a row's last gain
+    double cur_g = 0.0;
+    bool bin_ok = FUSE, violated = false;
+    double* slot = s_abs + a.fuse_abs_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane;     // slot k at slot[k * 64]
+    // deposits the column this lane is leaving (want) -- register entry first, then the occupied slots
+    auto flush = [&](bool want) __attribute__((always_inline)) {
+        rt2d_deposit(a.H, want, cur_ix * a.nz + cur_iz, want ? a.sign * rt2d_heat_val(cur_g) : 0.0, lane);
+        unsigned m = want ? occ : 0u;
+        while (__any(m != 0u)) {
+            const bool w = m != 0u;
+            const int k = w ? __ffs(m) - 1 : 0;
+            const int row = col_lo + ((k - col_lo) & 7);
+            const double g = w ? slot[k * RT2D_WAVE] : 0.0;
+            rt2d_deposit(a.H, w, cur_ix * a.nz + row, w ? a.sign * rt2d_heat_val(g) : 0.0, lane);
+            m &= m - 1u;
+        }
+    };
+    auto bin_point = [&](double bx, double bz, double g) __attribute__((always_inline)) {
+        int64_t ix64, iz64;
+        rt2d_cell_xz(a.geo, bx, bz, ix64, iz64);
+        const bool in_map = ix64 >= 0 && ix64 < a.nx && iz64 >= 0 && iz64 < a.nz;
+        const int ix = (int)ix64, iz = (int)iz64;
+        const bool first = cur_ix == INT32_MIN;
+        if (bin_ok && (!in_map || (!first && ix < cur_ix))) { bin_ok = false; violated = true; }
+        const bool newcol = bin_ok && !first && ix != cur_ix;
+        flush(newcol);
+        if (bin_ok) {
+            if (first || newcol) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; occ = 0u; }
+            else if (iz != cur_iz) {
+                slot[(cur_iz & 7) * RT2D_WAVE] = cur_g;                 // the row the ray leaves keeps its last gain
+                occ |= 1u << (cur_iz & 7);
+                occ &= ~(1u << (iz & 7));                               // an older visit of the row it enters is superseded
+                cur_iz = iz; col_lo = min(col_lo, iz); col_hi = max(col_hi, iz);
+                if (col_hi - col_lo >= 8) { bin_ok = false; violated = true; }
+            }
+            cur_g = g;
+        }
+    };
+    if (FUSE) {                                            // the source: G[0] = 0 (ray.py:347)
+        int64_t ix64, iz64;
+        rt2d_cell_xz(a.geo, x, z, ix64, iz64);
+        if (ix64 >= 0 && ix64 < a.nx && iz64 >= 0 && iz64 < a.nz) { cur_ix = (int)ix64; cur_iz = col_lo = col_hi = (int)iz64; }
+        else { bin_ok = false; violated = true; }
+    }
 
     // fmin / fmax through the bare instructions: in IEEE mode the compiler quiets every operand it cannot prove canonical
     // with an extra v_max_f64 x, x in front of each fmin / fmax, and the proof does not reach loop-invariant values across
@@ -303,6 +449,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     for (int i = 0; i < p.n_steps_max; ++i) {
         // step sizing (ray.py:153-154)
         const bool steep = fabs(dx_z) > dx_z_max;
+        if (POST >= 1) slope_max = fmax(slope_max, fabs(dx_z));
         {
             double s = p.dx_max;
             if (__any(steep)) {                  // wave-uniform: a wave of shallow rays never pays for the division
@@ -349,6 +496,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
         }
+        bool final_pt = false;                 // the point about to be accepted is the ray's last (max-rebounds)
         if (general) {
             if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
@@ -382,7 +530,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                 x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
                 z_new = hit_floor ? z_floor : z_ceil;
                 bool ok;
-                double s = rt2d_eval_quad(tab, slope_t, x_new, &ok);
+                double s = rt2d_eval_quad(tab_slope, slope_t, x_new, &ok);
                 if (!ok) { status = RT2D_RAY_ERR_INTERP; break; }
                 double u0 = 1.0, u1 = s;
                 double n0 = hit_floor ? -1 * u1 : u1;
@@ -405,40 +553,23 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
                     status = RT2D_RAY_ERR_REBOUND_LOG;
                 }
                 n_reb += 1;
-                if (CUTOFF) {                                                   // ray.py:350-362; applies from the NEXT point on
-                    double wavelength = c / p.cutoff_freq;
+                if (CUTOFF || FUSE) {                                           // ray.py:350-362; applies from the NEXT point on
+                    double wavelength = c / g_freq;
                     double rc = hit_floor ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, e.imp, z, nullptr))
                                           : rt2d_refcoef_surface(wavelength, ang);
                     g_pend = 10 * log10(rc);
                 }
                 if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
                 const int nrm = cold->n_rebounds_max;
-                if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended
-                    rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);
-                    if (FULL) {
-                        double ddx = x_new - x, ddz = z_new - z;
-                        double dL = sqrt(ddx * ddx + ddz * ddz);
-                        L += dL; T += dL / c_pt;
-                        if (has_target) tt.add(x_new, z_new, T, n_pts, tx);
-                    }
-                    if (POST >= 1) {
-                        min_x = fmin(min_x, x_new); max_x = fmax(max_x, x_new);
-                        min_z = fmin(min_z, z_new); max_z = fmax(max_z, z_new);
-                        mono &= !(x_new < x);
-                    }
-                    if (WRITE && n_pts < room) {
-                        px += RT2D_WAVE; pz += RT2D_WAVE;
-                        *px = x_new; *pz = z_new;
-                        if (pc) { pc += RT2D_WAVE; *pc = rt2d_eval_c(tab, e.cz, z_new); }
-                    }
-                    n_pts += 1;
+                if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended,
+                    rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);               // clipped into the bounds, and the ray ends
                     stop = RT2D_STOP_MAX_REBOUNDS;
-                    break;
+                    final_pt = true;
                 }
             }
 
             // all bounds (ray.py:225-230): any non-zero code stops, the point is not appended
-            if (x_new < e.range_min[0] || x_new > e.range_max[0] || z_new < e.range_min[1] || z_new > e.range_max[1]) {
+            if (!final_pt && (x_new < e.range_min[0] || x_new > e.range_max[0] || z_new < e.range_min[1] || z_new > e.range_max[1])) {
                 stop = rt2d_fit_code(e, x, x_new, z, z_new, dx_z);
                 if (stop) break;
             }
@@ -448,16 +579,19 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
 
         // accept the point (ray.py:235-247)
         bool cut = false;
-        if (FULL || CUTOFF) {
+        double g_pt = 0.0;
+        if (FULL || CUTOFF || FUSE) {
             double ddx = x_new - x, ddz = z_new - z;
             double dL = sqrt(ddx * ddx + ddz * ddz);                       // ray.py:271
             if (FULL) { L += dL; T += dL / c_pt; }                         // ray.py:272-275
-            if (CUTOFF) {
+            if (CUTOFF || FUSE) {
                 double rec[20];
-                rt2d_lookup<19>(gtab, e.absorb, z, rec);                   // factors at the START of the segment, ray.py:346
+                if (FUSE) rt2d_lookup<19>((const double*)s_abs, ab_lds, z, rec);
+                else rt2d_lookup<19>(gtab, e.absorb, z, rec);              // factors at the START of the segment, ray.py:346
                 double dG = -1 * rt2d_alpha(rec, z - rec[0], g_ff) / 1000 * dL;
                 g_S += dG;
-                cut = (g_S + g_A) < a.g_cut;
+                g_pt = g_S + g_A;
+                cut = CUTOFF && !final_pt && g_pt < a.g_cut;
                 g_A += g_pend; g_pend = 0.0;
             }
         }
@@ -478,6 +612,8 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
             if (pc) { pc += RT2D_WAVE; *pc = c; }
         }
         n_pts += 1;
+        if (FUSE) bin_point(x, z, g_pt);
+        if (final_pt) break;
         if (CUTOFF && cut) { stop = RT2D_STOP_POWER_CUTOFF; break; }
         x_dir = rt2d_sign(kx);
         // k1/k0 (ray.py:243).  In a wave whose rays all took a plain dx_max step, k0 is +-dx_max exactly and the quotient
@@ -497,6 +633,11 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
         if (i == p.n_steps_max - 1) stop = RT2D_STOP_MAX_ITER;                 // ray.py:257-259
     }
 
+    if (FUSE) {
+        flush(bin_ok && cur_ix != INT32_MIN);              // the column the ray ends in
+        if (a.irregular) a.irregular[r] = violated ? 1 : 0;
+        if (violated && a.n_violations) atomicAdd(a.n_violations, 1ull);
+    }
     const Rt2dRayOut& o = cold->out;
     const int64_t n = cold->n;
     if (o.n_pts) o.n_pts[r] = n_pts;
@@ -506,6 +647,7 @@ __global__ void __launch_bounds__(1024) rt2d_cast_kernel(const CastArgs a) {
     if (POST >= 1) {
         if (o.range) { o.range[r] = min_x; o.range[n + r] = min_z; o.range[2 * n + r] = max_x; o.range[3 * n + r] = max_z; }
         if (o.monotone) o.monotone[r] = mono ? 1 : 0;
+        if (o.slope_max) o.slope_max[r] = slope_max;
     }
     if (FULL) {
         if (o.L_end) o.L_end[r] = L;
@@ -882,54 +1024,6 @@ __global__ void __launch_bounds__(256) rt2d_dist_kernel(const double* X, const d
 // ------------------------------------------------------------------------------------------------------
 // heat map accumulation: one wave per ray; LDS hash "cell -> last step in that cell"
 #define HM_EMPTY 0xffffffffffffffffull
-
-__device__ __forceinline__ int64_t rt2d_floordiv(int64_t a, int64_t b) {
-    int64_t q = a / b;
-    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
-    return q;
-}
-
-// Cell indices of a point: ix = int(x) // res_x, iz = int(z) // (-res_z) (simulation.py:123-125: C truncation, then
-// Python floor division).  64-bit integer division costs ~150 instructions on this hardware and there are two per
-// point, so coordinates below 2^31 take a reciprocal multiply with an exact remainder fix-up instead: t and b are
-// integers, fma(-q, b, t) is exact, and q = floor(t * (1/b)) can only be one off when t/b is an integer.
-struct HeatGeom { int32_t res_x, res_z; double rx, rz, inv_rx, inv_rz, lim; };     // lim: |coordinate| bound of the fast division
-
-__device__ __forceinline__ int64_t rt2d_fdiv_pos(double t, double b, double inv_b) {     // floor(t / b), b > 0
-    double q = floor(t * inv_b);
-    double rem = fma(-q, b, t);
-    if (rem < 0.0) q -= 1.0; else if (rem >= b) q += 1.0;
-    return (int64_t)(int32_t)q;
-}
-
-__device__ __forceinline__ void rt2d_cell_xz(const HeatGeom& g, double x, double z, int64_t& ix, int64_t& iz) {
-    if (fabs(x) < g.lim && fabs(z) < g.lim) {
-        ix = rt2d_fdiv_pos(trunc(x), g.rx, g.inv_rx);
-        iz = rt2d_fdiv_pos(-trunc(z), g.rz, g.inv_rz);          // a // (-b) == (-a) // b
-    } else {
-        ix = rt2d_floordiv((int64_t)x, g.res_x);
-        iz = rt2d_floordiv((int64_t)z, -1 * (int64_t)g.res_z);
-    }
-}
-
-// flat cell index of a point, or -1 when it falls outside the map (functions.py:16; one negative wrap as NumPy does)
-__device__ __forceinline__ int64_t rt2d_cell(const HeatGeom& g, double x, double z, int64_t nz, int64_t size) {
-    int64_t ix, iz;
-    rt2d_cell_xz(g, x, z, ix, iz);
-    int64_t flat = ix * nz + iz;
-    if (flat < 0) flat += size;
-    if (flat < 0 || flat >= size) return -1;
-    return flat;
-}
-
-// vals = (10**(G/10))**-0.1 (ray.py:317, simulation.py:129).  While 10**(G/10) is a normal double this is 10**(-G/100)
-// to ~1e-15 relative (the heat-map tolerance is 1e-12) and one exp2 replaces two pows; outside that range the two
-// pows are evaluated as written so that underflow to 0 -> inf behaves as in the reference.
-__device__ __forceinline__ double rt2d_heat_val(double g) {
-    if (g > -3000.0 && g < 3000.0) return exp2(g * -0.033219280948873623);     // -log2(10)/100
-    double tmult = pow(10.0, g / 10);
-    return pow(tmult, -0.1);
-}
 
 __device__ __forceinline__ uint32_t rt2d_hash32(uint32_t k) { k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16; return k; }
 
@@ -1311,7 +1405,7 @@ int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out) {
 extern "C++" {
 static int post_level(const Rt2dRayOut& o) {
     if (o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin) return 2;
-    return (o.range || o.monotone) ? 1 : 0;
+    return (o.range || o.monotone || o.slope_max) ? 1 : 0;
 }
 
 template <bool WRITE, int POST, bool CUTOFF>
@@ -1414,6 +1508,55 @@ int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const d
     CastArgs a = make_cast_args(env, angles, n, src, params, init_slope, init_mult, out);
     a.tile_off = tile_off; a.X = X; a.Z = Z; a.C = C;
     return launch_cast<true>(env, a, (hipStream_t)stream);
+}
+
+int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* params,
+                          const double* init_slope, const double* init_mult, const uint8_t* ray_mask, double freq,
+                          const int32_t* res, const int32_t* shape, double sign, double* H, const Rt2dRayOut* out,
+                          uint8_t* irregular, int64_t* n_violations, void* stream) {
+    Rt2dRayOut none; memset(&none, 0, sizeof none);
+    if (!out) out = &none;
+    int32_t rc = check_cast(env, angles, n, src, params, init_slope, init_mult, out);
+    if (rc) return rc;
+    if (!res || !shape || !H) return fail("rt2d_cast_heatmap: null argument");
+    if (params->power_cutoff > 0) return fail("rt2d_cast_heatmap: power_cutoff is not supported by the fused kernel");
+    if (out->L_end || out->T_end || out->dist_to_target || out->step_target || out->T_target || out->margin || out->reb_step)
+        return fail("rt2d_cast_heatmap: only n_pts, stop_code, n_rebounds, status, range, monotone and slope_max are produced");
+    if (!(freq > 0)) return fail("rt2d_cast_heatmap: freq must be positive");
+    if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_cast_heatmap: resolution must be positive");
+    if (res[0] >= (1 << 20) || res[1] >= (1 << 20)) return fail("rt2d_cast_heatmap: resolution too coarse for the fused kernel");
+    if (shape[0] <= 0 || shape[1] <= 0 || (int64_t)shape[0] * shape[1] >= (1ll << 31)) return fail("rt2d_cast_heatmap: bad shape");
+    if (n == 0) return 0;
+    CastArgs a = make_cast_args(env, angles, n, src, params, init_slope, init_mult, out);
+    a.p.rebound_cap = 0;
+    a.ray_mask = ray_mask; a.H = H; a.nx = shape[0]; a.nz = shape[1]; a.heat_freq = freq; a.sign = sign;
+    a.geo.res_x = res[0]; a.geo.res_z = res[1]; a.geo.rx = res[0]; a.geo.rz = res[1];
+    a.geo.inv_rx = 1.0 / res[0]; a.geo.inv_rz = 1.0 / res[1]; a.geo.lim = 2147483648.0;
+    a.irregular = irregular; a.n_violations = (unsigned long long*)n_violations;
+    a.fuse_step_doubles = env->dev.dx_floor.off;                           // sound speed, floor, surface
+    a.fuse_abs_doubles = (env->dev.absorb.n_pieces + 1) * env->dev.absorb.stride;
+    a.fuse_abs_doubles += a.fuse_abs_doubles & 1;
+    a.lanes = RT2D_WAVE;
+    a.ceil_const = env->ceil_const;
+    const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
+    const size_t tab_bytes = ((size_t)a.fuse_step_doubles + a.fuse_abs_doubles) * sizeof(double);
+    const size_t per_wave = 8 * RT2D_WAVE * sizeof(double);
+    if (cold + tab_bytes + per_wave > RT2D_LDS_BUDGET)
+        return fail("rt2d_cast_heatmap: the sound-speed, floor, surface and absorption tables (%zu bytes) leave no room in LDS; "
+                    "use rt2d_cast_write + rt2d_gain + rt2d_heatmap_accumulate", tab_bytes);
+    int waves = (int)((RT2D_LDS_BUDGET - cold - tab_bytes) / per_wave);
+    if (waves > RT2D_FUSE_MAX_WAVES) waves = RT2D_FUSE_MAX_WAVES;
+    static const int waves_env = getenv("RT2D_FUSE_WAVES") ? atoi(getenv("RT2D_FUSE_WAVES")) : 0;
+    if (waves_env > 0 && waves_env < waves) waves = waves_env;
+    const int block = waves * RT2D_WAVE;
+    const size_t lds = cold + tab_bytes + (size_t)waves * per_wave;
+    const int64_t grid = (n + block - 1) / block;
+    if (grid > 0x7fffffff) return fail("too many rays for one launch");
+    auto k = env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, true> : rt2d_cast_kernel<false, true, 1, false, false, true>;
+    HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int64_t* total_out, void* stream_) {

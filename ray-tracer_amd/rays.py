@@ -96,6 +96,7 @@ class RayFan:
             self.status = torch.empty(n, **i32)
             self.range = torch.empty((4, n), **f64)
             self.monotone = torch.empty(n, dtype=torch.uint8, device=dev)
+            self.slope_max = torch.empty(n, **f64)
             self._scalars = None
             self.dist = torch.full((n,), float('nan'), **f64)
             self.step_target = torch.full((n,), -1, **i32)
@@ -115,6 +116,7 @@ class RayFan:
                 # produced on demand (_lazy_scalars) so that the main cast does not carry them through every step
                 out.range = self.range.data_ptr()
                 out.monotone = self.monotone.data_ptr()
+                out.slope_max = self.slope_max.data_ptr()
                 if self.target is not None:
                     out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
                     out.T_target = self.T_target.data_ptr()
@@ -349,10 +351,53 @@ class RayFan:
         base = torch.ones(self.n, dtype=torch.uint8, device=self.device) if ray_mask is None else (ray_mask != 0).to(torch.uint8)
         return base + 2 * (base * (inside & (self.monotone != 0)).to(torch.uint8))
 
+    def fused_mask(self, res, shape, ray_mask=None):
+        """uint8 mask of the rays rt2d_cast_heatmap may bin (include/rt2d.h): no error, x never decreases, bounding box
+        inside the map, at most 8 rows per column by the slope bound."""
+        torch = _torch()
+        rng = self.range
+        ok = ((self.status == 0) & (self.monotone != 0) & (rng[0] > -1) & (rng[3] < 1)
+              & (torch.div(torch.trunc(rng[2]), int(res[0]), rounding_mode='floor') < int(shape[0]))
+              & (torch.div(-torch.trunc(rng[1]), int(res[1]), rounding_mode='floor') < int(shape[1]))
+              & (torch.floor(self.slope_max * (float(res[0]) / float(res[1]))) + 2 <= 8))
+        if ray_mask is not None:
+            ok = ok & (ray_mask != 0)
+        return ok.to(torch.uint8)
+
+    def heatmap_accumulate_fused(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
+        """Heat map of a fan cast WITHOUT trajectories (store=False): the rays are propagated again by the fused kernel
+        (cast -> gain -> binning, nothing stored), except those it cannot bin exactly (fused_mask), which are cast with
+        trajectories as a small side fan and binned by the general kernels.  Same map as heatmap_accumulate."""
+        torch = _torch()
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
+            mask = self.fused_mask(res, shape, ray_mask)
+            res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
+            shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+            src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
+            p = self._params(0)
+            viol = torch.zeros(1, dtype=torch.int64, device=self.device)
+            _lib.check(L.rt2d_cast_heatmap(self.env.device_handle(self.device.index), self.angles_dev.data_ptr(), self.n, src,
+                                           C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
+                                           res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+            rest = torch.nonzero(sel & (mask == 0)).flatten()
+            self.last_slow_rays = int(rest.numel())
+            self.last_fused_violations = viol
+            if rest.numel():
+                init = None if self._init[0] is None else (self._init[0][rest].cpu().numpy(), self._init[1][rest].cpu().numpy())
+                kw = dict(self.kw)
+                side = RayFan(self.env, self.source, self.angles_dev[rest], target=None, store=True, device=self.device,
+                              init=init, **kw)
+                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped)
+
     def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True):
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
-        fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests)."""
-        self._need_store()
+        fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests).
+        A fan cast with store=False goes through the fused kernel (heatmap_accumulate_fused)."""
+        if not self.store:
+            return self.heatmap_accumulate_fused(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
         torch = _torch()
         L = _lib.lib()
         if freq not in self.G:

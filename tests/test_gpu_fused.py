@@ -1,0 +1,88 @@
+"""GPU: the fused cast -> gain -> heat-map kernel (rt2d_cast_heatmap) against the stored pipeline
+(rt2d_cast_write -> rt2d_gain -> rt2d_heatmap_accumulate), which the other GPU tests pin to the oracle and to the
+reference.  Same rays, same map: every cell to 1e-12 relative (the f64 atomics arrive in a different order)."""
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(rt, g, angles=None, freq=1, res=(50, 25), env=None, **over):
+    env = env or common.product_env(rt, g)
+    kw = common.prop_kwargs(g)
+    kw.update(over)
+    angles = g['fan_angles'] if angles is None else angles
+    stored = rt.Simulation2D(env, g['fan_source'])
+    stored.cast(angles, **kw)
+    fused = rt.Simulation2D(env, g['fan_source'])
+    fan = fused.cast(angles, store=False, **kw)
+    Hs, _ = stored.heatmap_full(resolution=list(res), freq=freq)
+    Hf, _ = fused.heatmap_full(resolution=list(res), freq=freq)
+    return Hs.cpu().numpy(), Hf.cpu().numpy(), fan, stored, fused
+
+
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+def test_fused_map_equals_stored_map(rt, name):
+    g = common.load(name)
+    Hs, Hf, fan, stored, fused = _maps(rt, g)
+    assert Hs.shape == Hf.shape
+    assert int(fan.last_fused_violations.item()) == 0
+    print(f'{name}: {fan.n - fan.last_slow_rays} of {fan.n} rays binned by the fused kernel, {fan.last_slow_rays} by the general path')
+    assert fan.last_slow_rays < fan.n // 2
+    rel = np.abs(Hf - Hs) / np.maximum(1e-300, np.abs(Hs))
+    assert np.array_equal(Hf == 0, Hs == 0)
+    assert rel[Hs != 0].max() < 1e-12
+    for cutoff in (.02, .5):
+        a = stored.heatmap(resolution=[50, 25], cutoff=cutoff)
+        b = fused.heatmap(resolution=[50, 25], cutoff=cutoff)
+        assert np.abs(a - b).max() < 1e-12
+
+
+@pytest.mark.parametrize('freq,res', [(1000., (50, 25)), (1, (20, 5)), (5000., (100, 10)), (1, (7, 3))])
+def test_fused_other_frequencies_and_cells(rt, freq, res):
+    """Finer cells put several rows and several points into one column (the slot path); a high frequency makes the
+    rebound losses matter."""
+    g = common.load('c2_fan999')
+    Hs, Hf, fan, _, _ = _maps(rt, g, angles=g['fan_angles'][::3], freq=freq, res=res)
+    assert int(fan.last_fused_violations.item()) == 0
+    print(f'freq {freq} res {res}: {fan.last_slow_rays} of {fan.n} rays through the general path')
+    assert np.array_equal(Hf == 0, Hs == 0)
+    both = np.isfinite(Hs) & (Hs != 0)
+    assert np.array_equal(np.isfinite(Hf), np.isfinite(Hs))
+    assert (np.abs(Hf - Hs)[both] / np.abs(Hs[both])).max() < 1e-12
+
+
+def test_fused_large_fan(rt):
+    """65 536 rays: the launch shape of real use (full workgroups, many waves per CU)."""
+    g = common.load('c2_fan999')
+    angles = -(np.arange(1 << 16) + 1) * (0.999 / (1 << 16))
+    Hs, Hf, fan, _, _ = _maps(rt, g, angles=angles)
+    assert int(fan.last_fused_violations.item()) == 0
+    assert np.array_equal(Hf == 0, Hs == 0)
+    assert (np.abs(Hf - Hs)[Hs != 0] / Hs[Hs != 0]).max() < 1e-12
+
+
+def test_fused_kernel_flags_a_ray_it_cannot_bin(rt):
+    """Called without the mask, the kernel must flag (not silently mis-bin) rays that move backwards."""
+    import ctypes as C
+    import torch
+    from ray_tracer_amd import _lib
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    fan = rt.RayFan(env, g['fan_source'], g['fan_angles'], store=False, **common.prop_kwargs(g))
+    n_back = int(((fan.monotone == 0) & (fan.status == 0)).sum().item())
+    assert n_back > 0
+    shape = (1600, 70)
+    H = torch.zeros(shape[0] * shape[1], dtype=torch.float64, device='cuda')
+    irr = torch.zeros(fan.n, dtype=torch.uint8, device='cuda')
+    viol = torch.zeros(1, dtype=torch.int64, device='cuda')
+    src = (C.c_double * 2)(*[float(v) for v in g['fan_source']])
+    p = fan._params(0)
+    _lib.check(_lib.lib().rt2d_cast_heatmap(env.device_handle(0), fan.angles_dev.data_ptr(), fan.n, src, C.byref(p), None, None,
+                                           None, 1.0, (C.c_int32 * 2)(50, 25), (C.c_int32 * 2)(*shape), 1.0, H.data_ptr(), None,
+                                           irr.data_ptr(), viol.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert int(viol.item()) == int(irr.sum().item()) >= n_back
+    assert bool((irr[(fan.monotone == 0) & (fan.status == 0)] == 1).all().item())
