@@ -192,6 +192,34 @@ def pmc_traffic(large):
     return (cand[-1] if large else cand[0])[1]['hbm_bytes'], os.path.relpath(files[-1], ROOT)
 
 
+def one_step_fused(rt, torch, env, source, angles_dev, ev=None, device=None):
+    """The same product, trajectories never stored: count pass (per-ray scalars, plot range) -> fused cast+gain+binning
+    for the rays it can bin exactly, stored path for the others -> normalise.  This is Simulation2D.cast(store=False)
+    + heatmap() spelled out so that the stages can be timed."""
+    from ray_tracer_amd import _lib, parallel
+    L = _lib.lib()
+    f64 = dict(dtype=torch.float64, device=device)
+    if ev: ev[0].record()
+    fan = rt.RayFan(env, source, angles_dev, store=False, device=device, **PROP)
+    if ev: ev[1].record()
+    okm = fan.status == 0
+    big = torch.finfo(torch.float64).max
+    rng = fan.range
+    lo = torch.minimum(torch.where(okm, rng[:2], torch.full_like(rng[:2], big)).amin(dim=1), torch.zeros(2, **f64))
+    hi = torch.maximum(torch.where(okm, rng[2:], torch.full_like(rng[2:], -big)).amax(dim=1), torch.zeros(2, **f64))
+    shape = parallel.heatmap_shape(lo.cpu().numpy(), hi.cpu().numpy(), RES)
+    H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)
+    fan.heatmap_accumulate_fused(H, RES, shape, freq=1)
+    if ev: ev[2].record()
+    outp = torch.empty(int(shape[0]) * int(shape[1]), **f64)
+    scratch = torch.empty(2, **f64)
+    shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+    _lib.check(L.rt2d_heatmap_finalize(H.data_ptr(), shape_c, .02, .5, outp.data_ptr(), scratch.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+    if ev: ev[3].record()
+    return fan, outp.view(int(shape[1]), int(shape[0]))
+
+
 def ray_steps_of(n_pts, status):
     ok = status == 0
     return int((n_pts[ok] - 1).sum().item())
@@ -312,7 +340,7 @@ def main():
         stages_l = Stages(torch)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(args.large_steps):
-            _, n_pts_l, status_l, _ = one_step(rt, torch, env, source, big_angles, stages=stages_l, device=device)
+            _, n_pts_l, status_l, hm_l = one_step(rt, torch, env, source, big_angles, stages=stages_l, device=device)
         torch.cuda.synchronize(); dtl = time.perf_counter() - t0
         sl = ray_steps_of(n_pts_l, status_l)
         stl = stages_l.summary()
@@ -327,6 +355,25 @@ def main():
                          'fp64_valu_frac': sl * FLOP_PER_STEP / (stl['cast_store'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                          'count_pass_steps_per_s': sl / (stl['cast_count'] * 1e-3)},
         }
+        # the fused pipeline on the same fan (no trajectory in HBM)
+        _, hm_f = one_step_fused(rt, torch, env, source, big_angles, device=device)
+        recs = []
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.large_steps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            fan_f, hm_f = one_step_fused(rt, torch, env, source, big_angles, ev=ev, device=device)
+            recs.append(ev)
+        torch.cuda.synchronize(); dtf = time.perf_counter() - t0
+        names = ('cast_count', 'fused_cast_gain_bin+rest', 'finalize')
+        stf = {nm: float(np.mean([e[k].elapsed_time(e[k + 1]) for e in recs])) for k, nm in enumerate(names)}
+        sf = ray_steps_of(fan_f.n_pts, fan_f.status)
+        result['large_fan_fused'] = {
+            'rays': nL, 'ray_steps': sf, 'value': sf * args.large_steps / dtf, 'unit': 'ray-steps/s',
+            's_per_heatmap': dtf / args.large_steps, 'stage_ms': stf,
+            'rays_binned_by_the_stored_path': int(fan_f.last_slow_rays),
+            'fused_violations': int(fan_f.last_fused_violations.item()),
+            'max_abs_diff_vs_stored_map': float((hm_f - hm_l).abs().max().item()),
+            'fp64_valu_frac': sf * (FLOP_PER_STEP + 30) / (stf['fused_cast_gain_bin+rest'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
         del big_angles
     if rank == 0:
         if world == 1 and not args.no_cpu:

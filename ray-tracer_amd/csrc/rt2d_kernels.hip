@@ -102,20 +102,36 @@ __device__ __forceinline__ double rt2d_heat_val(double g) {
 // mostly sit in the same cell at the same step: runs of adjacent depositing lanes with equal cells are summed first
 // (segmented inclusive scan) and the last lane of each run issues ONE atomic.  Callable from divergent code: only the
 // lanes that call take part, and nothing is read from a lane outside the caller's own run.
+// value of `v` in the lane CTRL points at (DPP: row_shr:n = 0x110 + n inside rows of 16 lanes, row_bcast:15 = 0x142 and
+// row_bcast:31 = 0x143 across rows); lanes without a source read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double rt2d_dpp(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
 __device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, double val, int lane) {
     const unsigned long long act = __ballot(want);
     if (act == 0) return;
-    const int c_prev = __shfl_up(cell, 1);
+    const int c_prev = __builtin_amdgcn_update_dpp(0, cell, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     const bool prev_in = lane > 0 && ((act >> (lane - 1)) & 1ull);
     const bool head = want && !(prev_in && c_prev == cell);
     const unsigned long long heads = __ballot(head);
     const int head_pos = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));    // head of this lane's run
+    // Segmented inclusive scan, all in the vector ALU: four shifts inside each row of 16 lanes, then the two row
+    // broadcasts that carry a run across rows.  A lane only adds a value that comes from its own run.
     double v = want ? val : 0.0;
-#pragma unroll
-    for (int off = 1; off < RT2D_WAVE; off <<= 1) {
-        const double v_up = __shfl_up(v, off);
-        if (want && lane - off >= head_pos) v += v_up;
-    }
+    const int in_row = lane & 15;
+    { const double u = rt2d_dpp<0x111, 0xf>(v); if (want && in_row >= 1 && lane - 1 >= head_pos) v += u; }
+    { const double u = rt2d_dpp<0x112, 0xf>(v); if (want && in_row >= 2 && lane - 2 >= head_pos) v += u; }
+    { const double u = rt2d_dpp<0x114, 0xf>(v); if (want && in_row >= 4 && lane - 4 >= head_pos) v += u; }
+    { const double u = rt2d_dpp<0x118, 0xf>(v); if (want && in_row >= 8 && lane - 8 >= head_pos) v += u; }
+    { const double u = rt2d_dpp<0x142, 0xa>(v);                                  // rows 1 and 3 <- lane 15 / 47
+      const int from = (lane & ~15) - 1; if (want && (lane & 16) && from >= head_pos) v += u; }
+    { const double u = rt2d_dpp<0x143, 0xc>(v);                                  // rows 2 and 3 <- lane 31
+      if (want && lane >= 32 && 31 >= head_pos) v += u; }
     const bool tail = want && (lane == RT2D_WAVE - 1 || !((act >> (lane + 1)) & 1ull) || ((heads >> (lane + 1)) & 1ull));
     if (tail) atomicAdd(&H[cell], v);
 }
@@ -146,6 +162,7 @@ struct CastArgs {
     unsigned long long* n_violations;
     int32_t fuse_step_doubles;    // blob prefix staged in LDS: sound speed, floor, surface (slopes are read from global)
     int32_t fuse_abs_doubles;     // length of the absorption table staged behind it
+    int32_t fuse_dbg;             // experiments (RT2D_FUSE_DBG): 1 = no cross-lane aggregation, 2 = no deposit, 4 = no exp2
 };
 
 // RN(a / b) for a divisor b > 0 whose correctly rounded reciprocal y = RN(1/b) is known (Markstein's correction
@@ -386,15 +403,21 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
     bool bin_ok = FUSE, violated = false;
     double* slot = s_abs + a.fuse_abs_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane;     // slot k at slot[k * 64]
     // deposits the column this lane is leaving (want) -- register entry first, then the occupied slots
+    auto dep = [&](bool want, int cell, double g) __attribute__((always_inline)) {
+        if (a.fuse_dbg & 2) return;
+        const double v = want ? a.sign * ((a.fuse_dbg & 4) ? g : rt2d_heat_val(g)) : 0.0;
+        if (a.fuse_dbg & 1) { if (want) atomicAdd(&a.H[cell], v); }
+        else rt2d_deposit(a.H, want, cell, v, lane);
+    };
     auto flush = [&](bool want) __attribute__((always_inline)) {
-        rt2d_deposit(a.H, want, cur_ix * a.nz + cur_iz, want ? a.sign * rt2d_heat_val(cur_g) : 0.0, lane);
+        dep(want, cur_ix * a.nz + cur_iz, cur_g);
         unsigned m = want ? occ : 0u;
         while (__any(m != 0u)) {
             const bool w = m != 0u;
             const int k = w ? __ffs(m) - 1 : 0;
             const int row = col_lo + ((k - col_lo) & 7);
             const double g = w ? slot[k * RT2D_WAVE] : 0.0;
-            rt2d_deposit(a.H, w, cur_ix * a.nz + row, w ? a.sign * rt2d_heat_val(g) : 0.0, lane);
+            dep(w, cur_ix * a.nz + row, g);
             m &= m - 1u;
         }
     };
@@ -1538,6 +1561,7 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     a.fuse_abs_doubles += a.fuse_abs_doubles & 1;
     a.lanes = RT2D_WAVE;
     a.ceil_const = env->ceil_const;
+    a.fuse_dbg = getenv("RT2D_FUSE_DBG") ? atoi(getenv("RT2D_FUSE_DBG")) : 0;
     const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
     const size_t tab_bytes = ((size_t)a.fuse_step_doubles + a.fuse_abs_doubles) * sizeof(double);
     const size_t per_wave = 8 * RT2D_WAVE * sizeof(double);
