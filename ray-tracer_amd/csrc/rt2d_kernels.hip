@@ -78,6 +78,17 @@ __device__ __forceinline__ void rt2d_cell_xz(const HeatGeom& g, double x, double
     }
 }
 
+// The same cell in 32-bit arithmetic, for callers that treat coordinates beyond 2^31 as an error (returns false there)
+__device__ __forceinline__ bool rt2d_cell_i32(const HeatGeom& g, double x, double z, int& ix, int& iz) {
+    const double tx = trunc(x), tz = -trunc(z);
+    double qx = floor(tx * g.inv_rx), qz = floor(tz * g.inv_rz);
+    const double remx = fma(-qx, g.rx, tx), remz = fma(-qz, g.rz, tz);
+    if (remx < 0.0) qx -= 1.0; else if (remx >= g.rx) qx += 1.0;
+    if (remz < 0.0) qz -= 1.0; else if (remz >= g.rz) qz += 1.0;
+    ix = (int)qx; iz = (int)qz;
+    return fabs(x) < 2147483648.0 && fabs(z) < 2147483648.0;
+}
+
 // flat cell index of a point, or -1 when it falls outside the map (functions.py:16; one negative wrap as NumPy does)
 __device__ __forceinline__ int64_t rt2d_cell(const HeatGeom& g, double x, double z, int64_t nz, int64_t size) {
     int64_t ix, iz;
@@ -91,8 +102,31 @@ __device__ __forceinline__ int64_t rt2d_cell(const HeatGeom& g, double x, double
 // vals = (10**(G/10))**-0.1 (ray.py:317, simulation.py:129).  While 10**(G/10) is a normal double this is 10**(-G/100)
 // to ~1e-15 relative (the heat-map tolerance is 1e-12) and one exp2 replaces two pows; outside that range the two
 // pows are evaluated as written so that underflow to 0 -> inf behaves as in the reference.
+// 2^t for |t| < 1000: t = n + f with n = rint(t), |f| <= 1/2 (the subtraction is exact); 2^f by the Taylor series of
+// e^(f ln 2) to degree 13 (truncation 3e-18 relative at |f| = 1/2) in FMA Horner form, then the exponent is added.
+// About 1e-16 relative, 19 instructions; the library exp2 spends ~110 on special cases this caller never meets.
+__device__ __forceinline__ double rt2d_exp2(double t) {
+    const double n = rint(t);
+    const double f = t - n;
+    double p = 0x1.816193166d0f9p-40;
+    p = fma(p, f, 0x1.c3bd650fc2986p-36);
+    p = fma(p, f, 0x1.e8cac7351bb25p-32);
+    p = fma(p, f, 0x1.e4cf5158b8ecap-28);
+    p = fma(p, f, 0x1.b5253d395e7c4p-24);
+    p = fma(p, f, 0x1.62c0223a5c824p-20);
+    p = fma(p, f, 0x1.ffcbfc588b0c7p-17);
+    p = fma(p, f, 0x1.430912f86c787p-13);
+    p = fma(p, f, 0x1.5d87fe78a6731p-10);
+    p = fma(p, f, 0x1.3b2ab6fba4e77p-7);
+    p = fma(p, f, 0x1.c6b08d704a0c0p-5);
+    p = fma(p, f, 0x1.ebfbdff82c58fp-3);
+    p = fma(p, f, 0x1.62e42fefa39efp-1);
+    p = fma(p, f, 1.0);
+    return ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ double rt2d_heat_val(double g) {
-    if (g > -3000.0 && g < 3000.0) return exp2(g * -0.033219280948873623);     // -log2(10)/100
+    if (g > -3000.0 && g < 3000.0) return rt2d_exp2(g * -0.033219280948873623);     // -log2(10)/100
     double tmult = pow(10.0, g / 10);
     return pow(tmult, -0.1);
 }
@@ -311,7 +345,8 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 // RayFan.fused_mask): then "last write wins" (functions.py:16) is local to the column a ray is in -- a register entry for
 // the row it is in, 8 LDS slots per lane for rows it has left but may come back to -- and the column is deposited when
 // the ray leaves it.  Slope tables and the impedance table are read from global memory (rebounds only) to make room.
-#define RT2D_FUSE_MAX_WAVES 12      // launch bound of the FUSE kernels: 3 waves per SIMD leave them 168 vector registers
+#define RT2D_FUSE_MAX_WAVES 8      // launch bound of the FUSE kernels: they want ~250 vector registers; at 12 waves (168
+                                   // registers) the spills cost more than the lost occupancy (27 vs 22 ms per 1M rays)
 template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC, bool FUSE = false>
 __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
@@ -422,10 +457,8 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
         }
     };
     auto bin_point = [&](double bx, double bz, double g) __attribute__((always_inline)) {
-        int64_t ix64, iz64;
-        rt2d_cell_xz(a.geo, bx, bz, ix64, iz64);
-        const bool in_map = ix64 >= 0 && ix64 < a.nx && iz64 >= 0 && iz64 < a.nz;
-        const int ix = (int)ix64, iz = (int)iz64;
+        int ix, iz;
+        const bool in_map = rt2d_cell_i32(a.geo, bx, bz, ix, iz) && (unsigned)ix < (unsigned)a.nx && (unsigned)iz < (unsigned)a.nz;
         const bool first = cur_ix == INT32_MIN;
         if (bin_ok && (!in_map || (!first && ix < cur_ix))) { bin_ok = false; violated = true; }
         const bool newcol = bin_ok && !first && ix != cur_ix;
@@ -443,10 +476,10 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
         }
     };
     if (FUSE) {                                            // the source: G[0] = 0 (ray.py:347)
-        int64_t ix64, iz64;
-        rt2d_cell_xz(a.geo, x, z, ix64, iz64);
-        if (ix64 >= 0 && ix64 < a.nx && iz64 >= 0 && iz64 < a.nz) { cur_ix = (int)ix64; cur_iz = col_lo = col_hi = (int)iz64; }
-        else { bin_ok = false; violated = true; }
+        int ix0, iz0;
+        if (rt2d_cell_i32(a.geo, x, z, ix0, iz0) && (unsigned)ix0 < (unsigned)a.nx && (unsigned)iz0 < (unsigned)a.nz) {
+            cur_ix = ix0; cur_iz = col_lo = col_hi = iz0;
+        } else { bin_ok = false; violated = true; }
     }
 
     // fmin / fmax through the bare instructions: in IEEE mode the compiler quiets every operand it cannot prove canonical
