@@ -854,12 +854,25 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
 #pragma unroll
         for (int k = 0; k < FCH; ++k) if (k < nf) a.G[(int64_t)(f0 + k) * a.total + base] = 0.0;
     }
-    double xn = 0.0, zn = 0.0;
-    if (np > 1) { xn = a.X[base + RT2D_WAVE]; zn = a.Z[base + RT2D_WAVE]; }
-    for (int s = 1; s < np; ++s) {
+    // the next GAIN_AHEAD points of the ray are in flight while one is worked on (a slot is refilled as soon as it is read).
+    // Measured on 1M rays: 1 ahead 6.9 ms, 4 ahead 8.4 ms -- the kernel is bound by its ~130 instructions per step, not by
+    // HBM latency, and the extra registers cost occupancy.
+    constexpr int GAIN_AHEAD = 1;
+    double xq[GAIN_AHEAD], zq[GAIN_AHEAD];
+#pragma unroll
+    for (int u = 0; u < GAIN_AHEAD; ++u) {
+        const bool live = 1 + u < np;
+        xq[u] = live ? a.X[base + (int64_t)(1 + u) * RT2D_WAVE] : 0.0;
+        zq[u] = live ? a.Z[base + (int64_t)(1 + u) * RT2D_WAVE] : 0.0;
+    }
+    for (int s0 = 1; s0 < np; s0 += GAIN_AHEAD) {
+#pragma unroll
+      for (int u = 0; u < GAIN_AHEAD; ++u) {
+        const int s = s0 + u;
+        if (s >= np) break;
         int64_t o = base + (int64_t)s * RT2D_WAVE;
-        double x = xn, z = zn;
-        if (s + 1 < np) { xn = a.X[o + RT2D_WAVE]; zn = a.Z[o + RT2D_WAVE]; }   // next point in flight during this step
+        double x = xq[u], z = zq[u];
+        if (s + GAIN_AHEAD < np) { xq[u] = a.X[o + GAIN_AHEAD * RT2D_WAVE]; zq[u] = a.Z[o + GAIN_AHEAD * RT2D_WAVE]; }
         double ddx = x - xp, ddz = z - zp;
         double dL = sqrt(ddx * ddx + ddz * ddz);
         // six depth factors at the START point of the segment (ray.py:346 uses XZ[:-1, 1])
@@ -897,6 +910,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
             if (a.G && k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = S[k] + A[k];
         }
         xp = x; zp = z;
+      }
     }
     if (a.G_end) {
 #pragma unroll
