@@ -390,7 +390,7 @@ class RayFan:
                 kw = dict(self.kw)
                 side = RayFan(self.env, self.source, self.angles_dev[rest], target=None, store=True, device=self.device,
                               init=init, **kw)
-                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped)
+                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=False)   # none of them suits the tile kernel
 
     def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True):
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
