@@ -72,7 +72,7 @@ class Stages:
 
 def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False, device=None):
     """The hot path once.  Returns (ray_steps, heat map (nz, nx) device tensor)."""
-    from ray_tracer_amd import _lib, parallel
+    from ray_tracer_amd import _lib, parallel, rays
     L = _lib.lib()
     stream = torch.cuda.current_stream().cuda_stream
     ev = stages.new_step() if stages is not None else None
@@ -107,8 +107,27 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
 
     room = 4096
     speculative = n_tiles * room * 64 * 16 <= (1 << 30)          # same policy as RayFan (ray-tracer_amd/rays.py)
+    padded = (not speculative and n_tiles * room * 64 * 16 <= rays.PADDED_BYTES
+              and n_tiles * room * 64 * 16 * 1.6 <= torch.cuda.mem_get_info(device)[0])
     done = False
     if ev: ev[0].record()
+    if padded:
+        # big fan: ONE storing pass into a padded layout that is kept (288 GB of HBM: untouched pages cost nothing)
+        if ev: ev[1].record(); ev[2].record()
+        tile_off = torch.arange(n_tiles + 1, dtype=torch.int64, device=device) * (room * 64)
+        total = n_tiles * room * 64
+        X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
+        _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(with_log(out)),
+                                     tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(), None, stream))
+        if ev: ev[3].record()
+        exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=device)
+        _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
+        longest, log_full = torch.stack((exact.diff().max(), (status == -2).any().to(torch.int64))).tolist()
+        done = longest <= room * 64 and not log_full
+        if not done:
+            del X, Z
+            tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=device)
+            total = C.c_int64(0)
     if speculative:
         # small fan: one storing pass into a provisional layout, exact layout, compaction copy
         if ev: ev[1].record(); ev[2].record()

@@ -25,6 +25,10 @@ TILE = 64
 HEATMAP_FAST_MIN_RAYS = int(os.environ.get('RT2D_HEATMAP_FAST_MIN_RAYS', 16384))    # same switch as the library's
 SPECULATIVE_ROOM = 4096          # points per ray a speculative single-pass cast reserves
 SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below this
+# Big fans: 288 GB of HBM make the counting pass optional.  The same single storing pass goes into a PADDED layout
+# (SPECULATIVE_ROOM points of room per ray) that is then kept as the fan's layout -- untouched pages cost nothing -- as
+# long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
+PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
 
 
 def _torch():
@@ -143,6 +147,7 @@ class RayFan:
             self.rebound_cap = 0
             self.tile_off = self.X = self.Z = self.Cpt = None
             self.total = 0
+            self.padded = False
             self.passes = 'count'
             if n == 0:
                 return
@@ -187,6 +192,29 @@ class RayFan:
                     self.passes = 'speculative'
                     return
                 del X0, Z0, C0
+            else:
+                room_p = min(int(self.kw['n_steps_max']) + 1, SPECULATIVE_ROOM)
+                padded_bytes = n_tiles * room_p * TILE * (24 if store_c else 16)
+                if padded_bytes <= PADDED_BYTES and padded_bytes * 1.6 <= torch.cuda.mem_get_info(dev)[0]:
+                    out = full_out()
+                    alloc_log(out, nrm + 1 if nrm > -1 else REBOUND_LOG_CAP_DEFAULT)
+                    off0 = torch.arange(n_tiles + 1, dtype=torch.int64, device=dev) * (room_p * TILE)
+                    X0 = torch.empty(n_tiles * room_p * TILE, **f64)
+                    Z0 = torch.empty(n_tiles * room_p * TILE, **f64)
+                    C0 = torch.empty(n_tiles * room_p * TILE, **f64) if store_c else None
+                    cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
+                    exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
+                    _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
+                    longest, log_full = torch.stack((exact.diff().max(), (self.status == _lib.RAY_ERR_REBOUND_LOG).any().to(torch.int64))).tolist()
+                    if longest <= room_p * TILE and not log_full:
+                        self.tile_off, self._tile_off_exact = off0, exact
+                        self.X, self.Z, self.Cpt = X0, Z0, C0
+                        self.total = n_tiles * room_p * TILE
+                        self._out = out
+                        self.padded = True
+                        self.passes = 'padded'
+                        return
+                    del X0, Z0, C0
 
             # pass 1: count points and rebounds only (no post-pass, no stores)
             cnt = _lib.Rt2dRayOut()
@@ -261,6 +289,40 @@ class RayFan:
         if not self.store:
             raise _lib.Rt2dError('this fan was cast with store=False: trajectories were not kept')
 
+    def _ensure_compact(self):
+        """Turns a padded layout (see PADDED_BYTES) into the exact one: X, Z, C and the gains kept so far are copied."""
+        if not self.padded:
+            return
+        torch = _torch()
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            f64 = dict(dtype=torch.float64, device=self.device)
+            exact = self._tile_off_exact
+            total = int(exact[-1].item())
+
+            def move(a, b, c=None):
+                na, nb = torch.empty(total, **f64), torch.empty(total, **f64)
+                nc = torch.empty(total, **f64) if c is not None else None
+                _lib.check(L.rt2d_traj_compact(self.tile_off.data_ptr(), exact.data_ptr(), self.n, a.data_ptr(), b.data_ptr(),
+                                               _ptr(c), na.data_ptr(), nb.data_ptr(), _ptr(nc), stream))
+                return na, nb, nc
+
+            X, Z, Cp = move(self.X, self.Z, self.Cpt)
+            freqs = list(self.G)
+            newG = {}
+            for k in range(0, len(freqs), 2):
+                pair = freqs[k:k + 2]
+                a = self.G[pair[0]]
+                b = self.G[pair[-1]]
+                na, nb, _ = move(a, b)
+                newG[pair[0]] = na
+                if len(pair) == 2:
+                    newG[pair[1]] = nb
+            self.X, self.Z, self.Cpt, self.G = X, Z, Cp, newG
+            self.tile_off, self.total, self.padded = exact, total, False
+            self._host.pop('tile_off', None)
+            self.passes = 'padded+compact'
     def ray_slice(self, tensor, i):
         """Points of ray i out of a tile-layout tensor (a strided device view, no copy)."""
         self._need_store()
@@ -270,6 +332,7 @@ class RayFan:
     def padded_host(self, tensor_x=None, tensor_z=None):
         """(X, Z, valid) as (n, max_pts) NumPy arrays, NaN-padded: the whole fan's points on the host."""
         self._need_store()
+        self._ensure_compact()
         X = self.X if tensor_x is None else tensor_x
         Z = self.Z if tensor_z is None else tensor_z
         n_pts, off = self.host('n_pts'), self.host('tile_off')
@@ -292,6 +355,7 @@ class RayFan:
     def post(self):
         if self._post is None:
             self._need_store()
+            self._ensure_compact()               # five more arrays of `total` elements: not in the padded layout
             torch = _torch()
             L = _lib.lib()
             with torch.cuda.device(self.device):
@@ -312,6 +376,8 @@ class RayFan:
         new = [f for f in dict.fromkeys(freqs) if f not in self.G_end]
         if not new:
             return
+        if self.padded and keep_arrays and len(new) + len(self.G) > 1:
+            self._ensure_compact()               # the padded layout only has room for one gain array beside X and Z
         L = _lib.lib()
         with torch.cuda.device(self.device):
             f64 = dict(dtype=torch.float64, device=self.device)
