@@ -87,6 +87,8 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     out.range = rng.data_ptr()
     mono = torch.empty(n, dtype=torch.uint8, device=device)
     out.monotone = mono.data_ptr()
+    smax = torch.empty(n, **f64)
+    out.slope_max = smax.data_ptr()
     src = (C.c_double * 2)(float(source[0]), float(source[1]))
     p = _lib.Rt2dParams()
     p.dx_max, p.dz_max, p.n_steps_max, p.n_rebounds_max, p.backprop = PROP['dx_max'], PROP['dz_max'], 100000, PROP['n_rebounds_max'], 1
@@ -157,10 +159,14 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
                                      tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(), None, stream))
         if ev: ev[3].record()
     if ev: ev[4].record()
-    G = torch.empty(total, **f64)
-    freq = torch.ones(1, **f64)
-    _lib.check(L.rt2d_gain(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap, n,
-                           freq.data_ptr(), 1, total, G.data_ptr(), None, stream))
+    # RT2D_BENCH_ONE_PASS=1: gain + binning in ONE pass over the trajectories (RayFan.heatmap_accumulate_stream) for big fans;
+    # slower than the two kernels today (17.5 vs 15.1 ms per 1M rays), kept as the form that needs no gain array
+    one_pass = n > 16384 and bool(os.environ.get('RT2D_BENCH_ONE_PASS'))
+    if not one_pass:
+        G = torch.empty(total, **f64)
+        freq = torch.ones(1, **f64)
+        _lib.check(L.rt2d_gain(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap, n,
+                               freq.data_ptr(), 1, total, G.data_ptr(), None, stream))
     if ev: ev[5].record()
     # plot range of the rays that did not fail (RayPack2D.add fold, origin included) -> heat-map shape
     okm = (status == 0)
@@ -172,17 +178,35 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         lo, hi = parallel.allreduce_plot_range(lo, hi, device=device)          # C1
     shape = parallel.heatmap_shape(lo, hi, RES)
     H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)
-    # ray_mask with the hint bit: x never decreases (from the cast) and the ray's bounding box is inside the map
-    mask = okm.to(torch.uint8)
-    if n > 16384:          # the tile kernel's range (rt2d_heatmap_accumulate); smaller fans use the general kernel
-        inside = ((rng[0] > -1) & (rng[3] < 1) & (torch.div(torch.trunc(rng[2]), RES[0], rounding_mode='floor') < int(shape[0]))
-                  & (torch.div(-torch.trunc(rng[1]), RES[1], rounding_mode='floor') < int(shape[1])))
-        mask = mask * (1 + 2 * (inside & (mono != 0)).to(torch.uint8))
-    work = torch.empty(n + 2, **i32)
     res_c = (C.c_int32 * 2)(*RES)
     shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
-    _lib.check(L.rt2d_heatmap_accumulate(X.data_ptr(), Z.data_ptr(), G.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), n,
-                                         mask.data_ptr(), res_c, shape_c, H.data_ptr(), None, work.data_ptr(), stream))
+    if one_pass:
+        # 1 = the one-pass kernel bins the ray (x never decreases, inside the map, <= 8 rows per column: RayFan.fused_mask);
+        # 2 = it only stores the ray's gain and the general kernel bins it afterwards
+        inside = ((rng[0] > -1) & (rng[3] < 1) & (torch.div(torch.trunc(rng[2]), RES[0], rounding_mode='floor') < int(shape[0]))
+                  & (torch.div(-torch.trunc(rng[1]), RES[1], rounding_mode='floor') < int(shape[1])))
+        regular = okm & inside & (mono != 0) & (torch.floor(smax * (RES[0] / RES[1])) + 2 <= 8)
+        rest = okm & ~regular
+        mask = regular.to(torch.uint8) + 2 * rest.to(torch.uint8)
+        n_rest = int(rest.sum().item())
+        G = torch.empty(total, **f64) if n_rest else None
+        viol = torch.zeros(1, dtype=torch.int64, device=device)
+        _lib.check(L.rt2d_gain_heatmap(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap,
+                                       n, 1.0, mask.data_ptr(), res_c, shape_c, H.data_ptr(), G.data_ptr() if n_rest else None,
+                                       None, None, viol.data_ptr(), stream))
+        if n_rest:
+            _lib.check(L.rt2d_heatmap_accumulate(X.data_ptr(), Z.data_ptr(), G.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), n,
+                                                 rest.to(torch.uint8).data_ptr(), res_c, shape_c, H.data_ptr(), None, None, stream))
+    else:
+        # ray_mask with the hint bit: x never decreases (from the cast) and the ray's bounding box is inside the map
+        mask = okm.to(torch.uint8)
+        if n > 16384:          # the tile kernel's range (rt2d_heatmap_accumulate); smaller fans use the general kernel
+            inside = ((rng[0] > -1) & (rng[3] < 1) & (torch.div(torch.trunc(rng[2]), RES[0], rounding_mode='floor') < int(shape[0]))
+                      & (torch.div(-torch.trunc(rng[1]), RES[1], rounding_mode='floor') < int(shape[1])))
+            mask = mask * (1 + 2 * (inside & (mono != 0)).to(torch.uint8))
+        work = torch.empty(n + 2, **i32)
+        _lib.check(L.rt2d_heatmap_accumulate(X.data_ptr(), Z.data_ptr(), G.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), n,
+                                             mask.data_ptr(), res_c, shape_c, H.data_ptr(), None, work.data_ptr(), stream))
     if collectives:
         parallel.allreduce_heatmap(H)                                          # C2
     if ev: ev[6].record()

@@ -208,6 +208,20 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
                   const int32_t* n_pts, const Rt2dRayOut* rebounds, int32_t rebound_cap, int64_t n,
                   const double* freqs, int32_t n_freqs, int64_t total, double* G, double* G_end, void* stream);
 
+/* Gain at ONE frequency and heat-map accumulation in one forward pass over stored trajectories (reference:
+ * ray.py:339-369 followed by simulation.py:120-131, functions.py:12-19): the gain of a point is binned the moment it is
+ * computed and never stored -- rt2d_gain + rt2d_heatmap_accumulate write 8 B per point and read 24 B back.
+ * ray_mask (device, n bytes, NULL = all 1): 1 = bin the ray here; it must meet the preconditions of rt2d_cast_heatmap
+ * (x never decreases, every point inside the map, at most 8 rows per column).  2 = only compute the ray's gain and
+ * store it to G (device, tile layout, `total` elements as for rt2d_gain; may be NULL when no ray has mask 2): the caller
+ * then bins these rays with rt2d_heatmap_accumulate.  0 = skip.  G_end (device, n, may be NULL): gain at the last point.
+ * irregular / n_violations: as for rt2d_cast_heatmap. */
+int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off,
+                          const int32_t* n_pts, const Rt2dRayOut* rebounds, int32_t rebound_cap, int64_t n,
+                          double freq, const uint8_t* ray_mask, const int32_t* res, const int32_t* shape,
+                          double* H, double* G, double* G_end, uint8_t* irregular, int64_t* n_violations,
+                          void* stream);
+
 /* Distance to a target from stored trajectories (reference: ray.py:282-287). dist: device, n. */
 int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,
                   const double* target, double* dist, void* stream);

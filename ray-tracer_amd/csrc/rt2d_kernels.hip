@@ -170,6 +170,72 @@ __device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, dou
     if (tail) atomicAdd(&H[cell], v);
 }
 
+// "Last write wins" for a ray whose heat-map column never decreases and whose points all fall inside the map, fed
+// point by point in path order (functions.py:16 semantics without storing the ray): such a ray can only come back to a
+// cell while it is still in the same column, so everything is local to the column it is in -- a register entry for the
+// row it is in, 8 slots per lane (direct-mapped by row & 7, in LDS: slot k of this lane at slot[k * 64]) for rows it has
+// left but may come back to -- and the column is deposited when the ray leaves it.  A ray that breaks a precondition
+// (column decreases, point outside the map, more than 8 rows inside one column) stops being binned and is flagged.
+struct BinTarget { double* H; HeatGeom geo; int32_t nx, nz; double sign; int32_t dbg; };
+
+struct RayBinner {
+    int cur_ix, cur_iz, col_lo, col_hi;
+    unsigned occ;                 // slots of the current column that hold a row's last gain
+    double cur_g;
+    bool ok, violated;
+    double* slot;
+
+    __device__ __forceinline__ void dep(const BinTarget& t, bool want, int cell, double g, int lane) const {
+        if (t.dbg & 2) return;
+        const double v = want ? t.sign * ((t.dbg & 4) ? g : rt2d_heat_val(g)) : 0.0;      // ray.py:317, simulation.py:129
+        if (t.dbg & 1) { if (want) atomicAdd(&t.H[cell], v); }
+        else rt2d_deposit(t.H, want, cell, v, lane);
+    }
+    // deposits the column this lane is leaving (want): register entry first, then the occupied slots
+    __device__ __forceinline__ void flush(const BinTarget& t, bool want, int lane) const {
+        dep(t, want, cur_ix * t.nz + cur_iz, cur_g, lane);
+        unsigned m = want ? occ : 0u;
+        while (__any(m != 0u)) {
+            const bool w = m != 0u;
+            const int k = w ? __ffs(m) - 1 : 0;
+            const int row = col_lo + ((k - col_lo) & 7);
+            const double g = w ? slot[k * RT2D_WAVE] : 0.0;
+            dep(t, w, cur_ix * t.nz + row, g, lane);
+            m &= m - 1u;
+        }
+    }
+    // first point of the ray (gain g)
+    __device__ __forceinline__ void start(const BinTarget& t, bool enabled, double* slot_, double x, double z, double g) {
+        slot = slot_; occ = 0u; cur_g = g; cur_ix = INT32_MIN; cur_iz = col_lo = col_hi = 0; ok = enabled; violated = false;
+        if (!enabled) return;
+        int ix, iz;
+        if (rt2d_cell_i32(t.geo, x, z, ix, iz) && (unsigned)ix < (unsigned)t.nx && (unsigned)iz < (unsigned)t.nz) {
+            cur_ix = ix; cur_iz = col_lo = col_hi = iz;
+        } else { ok = false; violated = true; }
+    }
+    // next point of the ray; callable from divergent code (the deposit only involves the calling lanes)
+    __device__ __forceinline__ void point(const BinTarget& t, double x, double z, double g, int lane) {
+        int ix, iz;
+        const bool in_map = rt2d_cell_i32(t.geo, x, z, ix, iz) && (unsigned)ix < (unsigned)t.nx && (unsigned)iz < (unsigned)t.nz;
+        if (ok && (!in_map || ix < cur_ix)) { ok = false; violated = true; }
+        const bool newcol = ok && ix != cur_ix;
+        flush(t, newcol, lane);
+        if (ok) {
+            if (newcol) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; occ = 0u; }
+            else if (iz != cur_iz) {
+                slot[(cur_iz & 7) * RT2D_WAVE] = cur_g;                 // the row the ray leaves keeps its last gain
+                occ |= 1u << (cur_iz & 7);
+                occ &= ~(1u << (iz & 7));                               // an older visit of the row it enters is superseded
+                cur_iz = iz; col_lo = min(col_lo, iz); col_hi = max(col_hi, iz);
+                if (col_hi - col_lo >= 8) { ok = false; violated = true; }
+            }
+            cur_g = g;
+        }
+    }
+    // after the last point: the column the ray ends in
+    __device__ __forceinline__ void finish(const BinTarget& t, int lane) const { flush(t, ok, lane); }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // stepping
 struct CastArgs {
@@ -190,14 +256,13 @@ struct CastArgs {
     int32_t lanes;                // rays per wave (1..64, power of two): small fans are spread over more waves
     // fused cast -> gain -> heat map (FUSE kernels)
     const uint8_t* ray_mask;      // n bytes, 0 = leave this ray out
-    double* H; HeatGeom geo; int32_t nx, nz;
-    double heat_freq, sign;
+    BinTarget bin;
+    double heat_freq;
     uint8_t* irregular;           // n bytes (may be NULL): 1 = the ray broke a precondition of the fused binning
     unsigned long long* n_violations;
     int32_t fuse_step_doubles;    // blob prefix staged in LDS: sound speed, floor, surface (slopes are read from global)
     int32_t fuse_abs_doubles;     // length of the absorption table staged behind it
-    int32_t fuse_dbg;             // experiments (RT2D_FUSE_DBG): 1 = no cross-lane aggregation, 2 = no deposit, 4 = no exp2
-};
+};                                // bin.dbg: experiments (RT2D_FUSE_DBG): 1 = no cross-lane aggregation, 2 = no deposit, 4 = no exp2
 
 // RN(a / b) for a divisor b > 0 whose correctly rounded reciprocal y = RN(1/b) is known (Markstein's correction
 // steps, each one FMA): q1 is a faithful quotient, and q1 + (a - b*q1)*y then rounds to the IEEE quotient, so the
@@ -431,56 +496,9 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
     if (CUTOFF || FUSE) { double f = g_freq / 1000; g_ff = f * f; }
     DevTable ab_lds = e.absorb; ab_lds.off = 0;            // the LDS copy of the absorption table starts at s_abs
 
-    // ---- fused binning state (FUSE) ----
-    int cur_ix = INT32_MIN, cur_iz = 0, col_lo = 0, col_hi = 0;
-    unsigned occ = 0;                                      // slots of the current column that hold a row's last gain
-    double cur_g = 0.0;
-    bool bin_ok = FUSE, violated = false;
-    double* slot = s_abs + a.fuse_abs_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane;     // slot k at slot[k * 64]
-    // deposits the column this lane is leaving (want) -- register entry first, then the occupied slots
-    auto dep = [&](bool want, int cell, double g) __attribute__((always_inline)) {
-        if (a.fuse_dbg & 2) return;
-        const double v = want ? a.sign * ((a.fuse_dbg & 4) ? g : rt2d_heat_val(g)) : 0.0;
-        if (a.fuse_dbg & 1) { if (want) atomicAdd(&a.H[cell], v); }
-        else rt2d_deposit(a.H, want, cell, v, lane);
-    };
-    auto flush = [&](bool want) __attribute__((always_inline)) {
-        dep(want, cur_ix * a.nz + cur_iz, cur_g);
-        unsigned m = want ? occ : 0u;
-        while (__any(m != 0u)) {
-            const bool w = m != 0u;
-            const int k = w ? __ffs(m) - 1 : 0;
-            const int row = col_lo + ((k - col_lo) & 7);
-            const double g = w ? slot[k * RT2D_WAVE] : 0.0;
-            dep(w, cur_ix * a.nz + row, g);
-            m &= m - 1u;
-        }
-    };
-    auto bin_point = [&](double bx, double bz, double g) __attribute__((always_inline)) {
-        int ix, iz;
-        const bool in_map = rt2d_cell_i32(a.geo, bx, bz, ix, iz) && (unsigned)ix < (unsigned)a.nx && (unsigned)iz < (unsigned)a.nz;
-        const bool first = cur_ix == INT32_MIN;
-        if (bin_ok && (!in_map || (!first && ix < cur_ix))) { bin_ok = false; violated = true; }
-        const bool newcol = bin_ok && !first && ix != cur_ix;
-        flush(newcol);
-        if (bin_ok) {
-            if (first || newcol) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; occ = 0u; }
-            else if (iz != cur_iz) {
-                slot[(cur_iz & 7) * RT2D_WAVE] = cur_g;                 // the row the ray leaves keeps its last gain
-                occ |= 1u << (cur_iz & 7);
-                occ &= ~(1u << (iz & 7));                               // an older visit of the row it enters is superseded
-                cur_iz = iz; col_lo = min(col_lo, iz); col_hi = max(col_hi, iz);
-                if (col_hi - col_lo >= 8) { bin_ok = false; violated = true; }
-            }
-            cur_g = g;
-        }
-    };
-    if (FUSE) {                                            // the source: G[0] = 0 (ray.py:347)
-        int ix0, iz0;
-        if (rt2d_cell_i32(a.geo, x, z, ix0, iz0) && (unsigned)ix0 < (unsigned)a.nx && (unsigned)iz0 < (unsigned)a.nz) {
-            cur_ix = ix0; cur_iz = col_lo = col_hi = iz0;
-        } else { bin_ok = false; violated = true; }
-    }
+    // ---- fused binning (FUSE): the source is the ray's first point, G[0] = 0 (ray.py:347) ----
+    RayBinner binner;
+    binner.start(a.bin, FUSE, s_abs + a.fuse_abs_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, x, z, 0.0);
 
     // fmin / fmax through the bare instructions: in IEEE mode the compiler quiets every operand it cannot prove canonical
     // with an extra v_max_f64 x, x in front of each fmin / fmax, and the proof does not reach loop-invariant values across
@@ -668,7 +686,7 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
             if (pc) { pc += RT2D_WAVE; *pc = c; }
         }
         n_pts += 1;
-        if (FUSE) bin_point(x, z, g_pt);
+        if (FUSE) binner.point(a.bin, x, z, g_pt, lane);
         if (final_pt) break;
         if (CUTOFF && cut) { stop = RT2D_STOP_POWER_CUTOFF; break; }
         x_dir = rt2d_sign(kx);
@@ -690,9 +708,9 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
     }
 
     if (FUSE) {
-        flush(bin_ok && cur_ix != INT32_MIN);              // the column the ray ends in
-        if (a.irregular) a.irregular[r] = violated ? 1 : 0;
-        if (violated && a.n_violations) atomicAdd(a.n_violations, 1ull);
+        binner.finish(a.bin, lane);                        // the column the ray ends in
+        if (a.irregular) a.irregular[r] = binner.violated ? 1 : 0;
+        if (binner.violated && a.n_violations) atomicAdd(a.n_violations, 1ull);
     }
     const Rt2dRayOut& o = cold->out;
     const int64_t n = cold->n;
@@ -1070,6 +1088,76 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
         for (int k = 0; k < nreb && s_at[k * RT2D_WAVE + lane] <= np - 1; ++k) A_end = s_loss[k * RT2D_WAVE + lane];
         a.G_end[(int64_t)fi * a.n + r] = S + A_end;
     }
+}
+
+
+// Gain at ONE frequency and heat-map binning in one forward pass over stored trajectories: the gain of a point is used
+// the moment it exists and never written (rt2d_gain + rt2d_heatmap_accumulate move 8 B per point out and 24 B back in).
+// Same gain expressions as rt2d_gain_kernel, same binning as the fused stepping kernel (RayBinner).  ray_mask: 1 = bin
+// here (the ray meets RayBinner's preconditions), 2 = only compute the gain and store it to G (the caller bins such a
+// ray with the general kernel), 0 = skip.
+struct GainHeatArgs {
+    GainArgs g; BinTarget bin; double freq;
+    const uint8_t* ray_mask; uint8_t* irregular; unsigned long long* n_violations;
+};
+
+__global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatArgs b) {
+    const GainArgs& a = b.g;
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
+    __syncthreads();
+    const double* tab = s_tab;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const uint8_t flags = b.ray_mask ? b.ray_mask[r] : (uint8_t)1;
+    if (!flags) return;
+    const bool binme = (flags & 1) != 0;
+    const DevTable& ab = a.env.absorb;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+    const double fr = b.freq;
+    const double f = fr / 1000;                                            // model_absorption.py:32
+    const double ff = f * f;
+    double S = 0.0, A = 0.0;
+    const int nreb = min(a.n_rebounds[r], a.rebound_cap);
+    int next_reb = 0;
+    int next_reb_at = (nreb > 0) ? a.reb_step[r] + 1 : 0x7fffffff;         // first point index that carries the loss
+    double xp = a.X[base], zp = a.Z[base];
+    RayBinner binner;
+    binner.start(b.bin, binme, s_tab + a.env.gain_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, xp, zp, 0.0);
+    if (!binme && a.G) a.G[base] = 0.0;
+    double xn = 0.0, zn = 0.0;
+    if (np > 1) { xn = a.X[base + RT2D_WAVE]; zn = a.Z[base + RT2D_WAVE]; }
+    for (int s = 1; s < np; ++s) {
+        const int64_t o = base + (int64_t)s * RT2D_WAVE;
+        const double x = xn, z = zn;
+        if (s + 1 < np) { xn = a.X[o + RT2D_WAVE]; zn = a.Z[o + RT2D_WAVE]; }   // next point in flight during this step
+        double ddx = x - xp, ddz = z - zp;
+        double dL = sqrt(ddx * ddx + ddz * ddz);
+        double rec[20];
+        rt2d_lookup<19>(tab, ab, zp, rec);                                  // factors at the START of the segment, ray.py:346
+        while (s >= next_reb_at) {                                          // ray.py:350-362
+            int64_t kk = (int64_t)next_reb * a.n + r;
+            double wavelength = a.reb_velocity[kk] / fr;
+            double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
+                ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr))
+                : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
+            A += 10 * log10(rc);
+            ++next_reb;
+            next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
+        }
+        double dG = -1 * rt2d_alpha(rec, zp - rec[0], ff) / 1000 * dL;      // ray.py:346
+        S += dG;                                                           // ray.py:347
+        const double g = S + A;
+        if (binme) binner.point(b.bin, x, z, g, lane);
+        else if (a.G) a.G[o] = g;
+        xp = x; zp = z;
+    }
+    binner.finish(b.bin, lane);
+    if (b.irregular) b.irregular[r] = binner.violated ? 1 : 0;
+    if (binner.violated && b.n_violations) atomicAdd(b.n_violations, 1ull);
+    if (a.G_end) a.G_end[r] = S + A;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1533,6 +1621,15 @@ static int32_t launch_cast(rt2d_env_t env, const CastArgs& a, hipStream_t stream
 }
 }  // extern "C++"
 
+static BinTarget make_bin_target(double* H, const int32_t* res, const int32_t* shape, double sign) {
+    BinTarget t; memset(&t, 0, sizeof t);
+    t.H = H; t.nx = shape[0]; t.nz = shape[1]; t.sign = sign;
+    t.geo.res_x = res[0]; t.geo.res_z = res[1]; t.geo.rx = res[0]; t.geo.rz = res[1];
+    t.geo.inv_rx = 1.0 / res[0]; t.geo.inv_rz = 1.0 / res[1]; t.geo.lim = 2147483648.0;
+    t.dbg = getenv("RT2D_FUSE_DBG") ? atoi(getenv("RT2D_FUSE_DBG")) : 0;
+    return t;
+}
+
 static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* p,
                           const double* init_slope, const double* init_mult, const Rt2dRayOut* out) {
     if (!env || !src || !p || !out) return fail("rt2d_cast: null argument");
@@ -1599,16 +1696,14 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     if (n == 0) return 0;
     CastArgs a = make_cast_args(env, angles, n, src, params, init_slope, init_mult, out);
     a.p.rebound_cap = 0;
-    a.ray_mask = ray_mask; a.H = H; a.nx = shape[0]; a.nz = shape[1]; a.heat_freq = freq; a.sign = sign;
-    a.geo.res_x = res[0]; a.geo.res_z = res[1]; a.geo.rx = res[0]; a.geo.rz = res[1];
-    a.geo.inv_rx = 1.0 / res[0]; a.geo.inv_rz = 1.0 / res[1]; a.geo.lim = 2147483648.0;
+    a.ray_mask = ray_mask; a.heat_freq = freq;
+    a.bin = make_bin_target(H, res, shape, sign);
     a.irregular = irregular; a.n_violations = (unsigned long long*)n_violations;
     a.fuse_step_doubles = env->dev.dx_floor.off;                           // sound speed, floor, surface
     a.fuse_abs_doubles = (env->dev.absorb.n_pieces + 1) * env->dev.absorb.stride;
     a.fuse_abs_doubles += a.fuse_abs_doubles & 1;
     a.lanes = RT2D_WAVE;
     a.ceil_const = env->ceil_const;
-    a.fuse_dbg = getenv("RT2D_FUSE_DBG") ? atoi(getenv("RT2D_FUSE_DBG")) : 0;
     const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
     const size_t tab_bytes = ((size_t)a.fuse_step_doubles + a.fuse_abs_doubles) * sizeof(double);
     const size_t per_wave = 8 * RT2D_WAVE * sizeof(double);
@@ -1720,6 +1815,36 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
                                   : fch == 2 ? rt2d_gain_kernel<2> : rt2d_gain_kernel<1>;
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(block), lds, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+
+int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                          const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
+                          const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,
+                          uint8_t* irregular, int64_t* n_violations, void* stream) {
+    if (!env || !X || !Z || !tile_off || !n_pts || !reb || !res || !shape || !H) return fail("rt2d_gain_heatmap: null argument");
+    if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
+        return fail("rt2d_gain_heatmap: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
+    if (n < 0) return fail("rt2d_gain_heatmap: negative count");
+    if (!(freq > 0)) return fail("rt2d_gain_heatmap: freq must be positive");
+    if (res[0] <= 0 || res[1] <= 0 || res[0] >= (1 << 20) || res[1] >= (1 << 20)) return fail("rt2d_gain_heatmap: bad resolution");
+    if (shape[0] <= 0 || shape[1] <= 0 || (int64_t)shape[0] * shape[1] >= (1ll << 31)) return fail("rt2d_gain_heatmap: bad shape");
+    if (n == 0) return 0;
+    GainHeatArgs b; memset(&b, 0, sizeof b);
+    GainArgs& a = b.g;
+    a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts;
+    a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
+    a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
+    a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1; a.G = G; a.G_end = G_end;
+    b.bin = make_bin_target(H, res, shape, 1.0);
+    b.freq = freq; b.ray_mask = ray_mask; b.irregular = irregular; b.n_violations = (unsigned long long*)n_violations;
+    const int block = (n <= 64 * 512) ? 64 : 512;
+    const size_t lds = ((size_t)env->dev.gain_doubles + (size_t)(block / RT2D_WAVE) * 8 * RT2D_WAVE) * sizeof(double);
+    if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain_heatmap: absorption tables do not fit in LDS");
+    HIP_OK(hipFuncSetAttribute((const void*)rt2d_gain_heatmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rt2d_gain_heatmap_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -458,12 +458,46 @@ class RayFan:
                               init=init, **kw)
                 side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=False)   # none of them suits the tile kernel
 
-    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True):
+    def heatmap_accumulate_stream(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
+        """Gain and binning in ONE forward pass over the stored trajectories (rt2d_gain_heatmap): the gain array is never
+        written for the rays that pass can bin (fused_mask); the others get their gain stored by the same pass and are
+        binned by the general kernel.  Same map as populate(freq) + heatmap_accumulate."""
+        self._need_store()
+        torch = _torch()
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
+            m = self.fused_mask(res, shape, ray_mask)
+            rest = sel & (m == 0)
+            m = m + 2 * rest.to(torch.uint8)
+            n_rest = int(rest.sum().item())
+            G = torch.empty(self.total, dtype=torch.float64, device=self.device) if n_rest else None
+            viol = torch.zeros(1, dtype=torch.int64, device=self.device)
+            res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
+            shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+            _lib.check(L.rt2d_gain_heatmap(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
+                                           self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap,
+                                           self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(), _ptr(G), None, None,
+                                           viol.data_ptr(), stream))
+            if n_rest:
+                _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), G.data_ptr(), self.tile_off.data_ptr(),
+                                                     self.n_pts.data_ptr(), self.n, rest.to(torch.uint8).data_ptr(), res_c, shape_c,
+                                                     H.data_ptr(), _ptr(dropped), None, stream))
+            self.last_slow_rays = n_rest
+            self.last_fused_violations = viol
+
+    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True, stream=None):
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
         fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests).
+        stream=True: gain + binning in one pass (heatmap_accumulate_stream): the gain array (8 B per point) is never
+        allocated.  Off by default: measured on 1M rays the one-pass kernel (214 vector registers, 8 waves per CU) takes
+        17.5 ms against 6.9 + 8.2 ms for rt2d_gain followed by the tile kernel.
         A fan cast with store=False goes through the fused kernel (heatmap_accumulate_fused)."""
         if not self.store:
             return self.heatmap_accumulate_fused(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
+        if stream:
+            return self.heatmap_accumulate_stream(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
         torch = _torch()
         L = _lib.lib()
         if freq not in self.G:

@@ -105,7 +105,7 @@ class Simulation2D:
                 mask = torch.zeros(fan.n, dtype=torch.uint8, device=device)
                 mask[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=device)] = 1
             fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True),
-                                   hint=kwargs.get('hint', True))
+                                   hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
         if dist_on:                                                       # C2: sum of the ranks' maps
             parallel.allreduce_heatmap(H)
             parallel._all_reduce(dropped, parallel._dist().ReduceOp.SUM)

@@ -1,0 +1,48 @@
+"""GPU: gain + binning in one pass over stored trajectories (rt2d_gain_heatmap) against rt2d_gain followed by
+rt2d_heatmap_accumulate, which the other GPU tests pin to the oracle and to the reference."""
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(rt, g, angles=None, freq=1, res=(50, 25)):
+    env = common.product_env(rt, g)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    fan = sim.cast(g['fan_angles'] if angles is None else angles, **common.prop_kwargs(g))
+    Hs, _ = sim.heatmap_full(resolution=list(res), freq=freq, stream=True)
+    Hs = Hs.cpu().numpy()
+    slow, viol = fan.last_slow_rays, int(fan.last_fused_violations.item())
+    assert freq not in fan.G                       # the one-pass form never materialises the gain array
+    Hr, _ = sim.heatmap_full(resolution=list(res), freq=freq, stream=False)
+    return Hs, Hr.cpu().numpy(), fan, slow, viol
+
+
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+def test_stream_map_equals_two_pass_map(rt, name):
+    Hs, Hr, fan, slow, viol = _both(rt, common.load(name))
+    assert viol == 0 and slow < fan.n // 2
+    assert np.array_equal(Hs == 0, Hr == 0)
+    assert (np.abs(Hs - Hr)[Hr != 0] / Hr[Hr != 0]).max() < 1e-12
+
+
+@pytest.mark.parametrize('freq,res', [(1000., (50, 25)), (1, (20, 5)), (5000., (100, 10)), (1, (7, 3))])
+def test_stream_other_frequencies_and_cells(rt, freq, res):
+    g = common.load('c2_fan999')
+    Hs, Hr, fan, slow, viol = _both(rt, g, angles=g['fan_angles'][::3], freq=freq, res=res)
+    assert viol == 0
+    assert np.array_equal(Hs == 0, Hr == 0) and np.array_equal(np.isfinite(Hs), np.isfinite(Hr))
+    both = np.isfinite(Hr) & (Hr != 0)
+    assert (np.abs(Hs - Hr)[both] / np.abs(Hr[both])).max() < 1e-12
+
+
+def test_stream_large_fan_padded_layout(rt):
+    g = common.load('c2_fan999')
+    angles = -(np.arange(1 << 16) + 1) * (0.999 / (1 << 16))
+    Hs, Hr, fan, slow, viol = _both(rt, g, angles=angles)
+    assert fan.passes == 'padded' and viol == 0
+    assert np.array_equal(Hs == 0, Hr == 0)
+    assert (np.abs(Hs - Hr)[Hr != 0] / Hr[Hr != 0]).max() < 1e-12
