@@ -134,6 +134,17 @@ class Simulation2D:
                                                         scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return out if kwargs.get('as_tensor', False) else out.cpu().numpy()
 
+    def heatmaps(self, freqs, **kwargs):
+        """One heat map per frequency (BASELINE config 4: an array of frequencies, frequency-dependent rebound loss).
+        The gains of all frequencies are populated by ONE launch (eight frequencies per lane share the six absorption
+        table look-ups of a point), then each map is binned and normalised as ``heatmap(freq=f)`` does.
+        Returns {freq: (nz, nx) array}."""
+        freqs = list(freqs)
+        pack = self.raypacks[kwargs.get('pack', self.pack_default)]
+        if all(fan.store for fan, _ in pack.segments()):
+            pack.populate(*freqs)
+        return {f: self.heatmap(freq=f, **kwargs) for f in freqs}
+
     def plot(self, fig, **kwargs):
         pack = kwargs.pop('pack', self.pack_default)
         for ray in self.raypacks[pack].rays:

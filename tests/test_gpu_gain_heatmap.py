@@ -254,3 +254,26 @@ def test_gain_two_phase_equals_one_pass(rt, monkeypatch):
         for i in range(0, fan.n, 37):
             a, b = fan.ray_slice(fan.G[f], i).cpu().numpy(), fan1.ray_slice(fan1.G[f], i).cpu().numpy()
             assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_heatmaps_for_an_array_of_frequencies(rt, orc):
+    """Config 4: one map per frequency from one batched gain launch; each equals the oracle's map over the GPU's own
+    points at that frequency (so the frequency-dependent rebound losses are the oracle's)."""
+    g = common.load('c4_multifreq')
+    env = common.product_env(rt, g)
+    oenv = common.oracle_env_from_product(orc, env)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    fan = sim.cast(g['fan_angles'], **common.prop_kwargs(g))
+    freqs = [float(f) for f in g['fan_freqs'][[0, 5, 21, 63]]]
+    maps = sim.heatmaps(freqs, resolution=[50, 25], cutoff=.1)
+    assert set(fan.G) >= set(freqs)
+    rays = [r for r in _oracle_rays_from_fan(orc, rt, fan) if r.status == 0]
+    for r in rays:
+        _oracle_post(orc, oenv, r)
+    for f in freqs:
+        _, plot_ref, _ = orc.heatmap(oenv, rays, res=(50, 25), cutoff=.1, freq=f)
+        assert maps[f].shape == plot_ref.shape
+        fin = np.isfinite(plot_ref)
+        assert np.array_equal(np.isfinite(maps[f]), fin)
+        assert np.abs(maps[f] - plot_ref)[fin].max() < 1e-11
+    assert np.nanmax(np.abs(maps[freqs[0]] - maps[freqs[1]])) > 1e-3           # the maps do depend on the frequency
