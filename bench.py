@@ -72,6 +72,7 @@ class Stages:
 
 def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False, device=None):
     """The hot path once.  Returns (ray_steps, heat map (nz, nx) device tensor)."""
+    import torch.distributed  # noqa: F401
     from ray_tracer_amd import _lib, parallel, rays
     L = _lib.lib()
     stream = torch.cuda.current_stream().cuda_stream
@@ -173,9 +174,11 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     big = torch.finfo(torch.float64).max
     lo = torch.minimum(torch.where(okm, rng[:2], torch.full_like(rng[:2], big)).amin(dim=1), torch.zeros(2, **f64))
     hi = torch.maximum(torch.where(okm, rng[2:], torch.full_like(rng[2:], -big)).amax(dim=1), torch.zeros(2, **f64))
-    lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+    ext = torch.cat((-lo, hi))                                                 # one collective, one device -> host read
     if collectives:
-        lo, hi = parallel.allreduce_plot_range(lo, hi, device=device)          # C1
+        parallel._all_reduce(ext, torch.distributed.ReduceOp.MAX)              # C1
+    ext = ext.cpu().numpy()
+    lo, hi = -ext[:2], ext[2:]
     shape = parallel.heatmap_shape(lo, hi, RES)
     H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)
     res_c = (C.c_int32 * 2)(*RES)
