@@ -271,7 +271,7 @@ def ray_steps_of(n_pts, status):
     return int((n_pts[ok] - 1).sum().item())
 
 
-def cpu_baseline(seconds=4.0):
+def cpu_baseline(seconds=12.0):
     """oracle/rt2d_oracle.c (scalar port of the reference's algorithm) on this host, 1 core, same C2 fan."""
     from oracle import oracle as orc
     xs = np.linspace(0., 75000., 3001)
