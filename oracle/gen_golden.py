@@ -292,9 +292,47 @@ def t2():
     save('t2_single', spec, fan_dict([0., 0.], [-1.], freqs), out)
 
 
+def synth_signal(n=4096, sample_rate=8000.):
+    """Deterministic test signal for the eigenray filter (the reference's WAV inputs are absent from its tree): a
+    linear chirp 50 Hz -> 3 kHz plus seeded noise, Hann-tapered."""
+    rng = np.random.default_rng(7)
+    t = np.arange(n) / sample_rate
+    chirp = np.sin(2 * np.pi * (50. * t + 0.5 * (2950. / t[-1]) * t * t))
+    return sample_rate, (chirp + 0.1 * rng.normal(size=n)) * np.hanning(n)
+
+
+def f5():
+    """EigenraySim2D.get_filter_NEW (simulation.py:410-480) on the c5 environment: per-ray target products
+    (gen_filter, ray.py:382-405) and the filtered, time-offset, summed signal."""
+    fl = LinearFloor([0., 50000.], [-1000., -1000.])
+    ce = LinearFloor([0., 50000.], [0., 0.])
+    spec = env_spec(fl, ce, [0., -1001.], [50000., 1.])
+    env = make_env(spec)
+    source, target = np.array([0., -50.]), np.array([12000., -600.])
+    sim = EigenraySim2D(env, source, target, 5, 4, n_rays_scan=200, scan_angle_min=-0.4, scan_angle_max=0.4,
+                        dx_max=50., dz_max=25., verbose=True, verbose_depth_max=0)
+    freqs = np.linspace(10., 4000., 40)
+    filt = sim.get_filter_NEW(*freqs)
+    sr, sig = synth_signal()
+    sr_out, out = filt(sr, sig)
+    pack = sim.raypacks[sim.pack_default]
+    angles = np.sort(list(pack.angles.keys()))
+    T_t, Tm_t = [], []
+    for a in angles:
+        T, Tm = pack.angles[a].gen_filter(target)
+        T_t.append(T); Tm_t.append(Tm)
+    dd = {f'env_{k}': v for k, v in spec.items()}
+    dd.update(source=source, target=target, n_rays=np.int64(5), n_rebounds_max=np.int64(4), n_rays_scan=np.int64(200),
+              scan_angle_min=np.float64(-0.4), scan_angle_max=np.float64(0.4), dx_max=np.float64(50.), dz_max=np.float64(25.),
+              freqs=freqs, sample_rate=np.float64(sr), signal=sig, filtered=out, angles=angles,
+              T_target=np.array(T_t), Tmult_target=np.array(Tm_t))
+    np.savez_compressed(os.path.join(GOLD, 'f5_filter.npz'), **dd)
+    print('wrote f5_filter.npz', out.shape, np.abs(out).max(), np.array(T_t))
+
+
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['c1', 'c2', 'c3', 'c4', 'c5', 't2']
+    which = sys.argv[1:] or ['c1', 'c2', 'c3', 'c4', 'c5', 't2', 'f5']
     for w in which:
         t = time.time()
         globals()[w]()

@@ -153,8 +153,8 @@ class Simulation2D:
 
 
 class EigenraySim2D(Simulation2D):
-    """Sweep + refine search of the rays that connect source and target (reference: simulation.py:158-314).
-    The FFT filter synthesis of the reference (get_filter*) is outside this path."""
+    """Sweep + refine search of the rays that connect source and target (reference: simulation.py:158-314), and the
+    eigenray filter built from them (get_filter_NEW, simulation.py:410-480)."""
 
     _PROP_KEYS = tuple(RayFan.PROPAGATE_DEFAULTS)
 
@@ -292,3 +292,53 @@ class EigenraySim2D(Simulation2D):
             if self.verbose:
                 print(f'{self._vi}Refine #{self.n_refines} mean distance: {self.dist_avg}')
             self.pack_default = pack_refine
+
+    # -- eigenray filter (reference: simulation.py:410-480) ------------------------------------------------
+    def target_products(self, *freqs, **kwargs):
+        """Per ray of the pack, in increasing angle: travel time to the target and transmittance at every frequency
+        (Ray2D.gen_filter, ray.py:382-405).  Returns (angles (n,), T_target (n,), Tmult_target (n, F))."""
+        raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
+        angles_sorted = np.sort(list(raypack.angles.keys()))
+        T_t, Tm_t = [], []
+        for angle in angles_sorted:
+            ray = raypack.angles[angle]
+            ray.populate_NEW(*freqs)                      # one batched gain launch per fan, then views
+            T_target, Tmult_target = ray.gen_filter(self.target)
+            T_t.append(T_target)
+            Tm_t.append(Tmult_target)
+        return angles_sorted, np.asarray(T_t, dtype=np.float64), np.asarray(Tm_t, dtype=np.float64)
+
+    def get_filter_NEW(self, *freqs, **kwargs):
+        """Filter that turns an emitted signal into the signal received at the target: every eigenray contributes the
+        signal weighted per frequency by its transmittance, delayed by its travel time (reference: simulation.py:410-480).
+        The returned ``filter(sample_rate, signal)`` runs on the GPU: one forward FFT, the rays' spectra as one
+        (n_rays, n_samples) batch, one batched inverse FFT (rocFFT through torch.fft), then the delayed sum in the
+        reference's order.  Returns (sample_rate, filtered signal) like the reference."""
+        torch = _torch()
+        rf = np.array(freqs, dtype=np.float64)
+        _, T_t, Tm_t = self.target_products(*freqs, **kwargs)
+        T_target_min, T_target_max = np.min(T_t), np.max(T_t)
+        T_stretch_total = T_target_max - T_target_min
+        device = torch.device('cuda', torch.cuda.current_device())
+        xp = torch.from_numpy(np.concatenate((-1 * rf[::-1], rf))).to(device)                    # simulation.py:470
+        fp = torch.from_numpy(np.concatenate((Tm_t[:, ::-1], Tm_t), axis=1)).to(device)          # (n_rays, 2F)
+
+        def filter(sample_rate, signal):
+            signal = np.asarray(signal)
+            n_samples = signal.shape[0]
+            data_add = int(np.ceil(T_stretch_total * sample_rate))
+            yf = torch.fft.fft(torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float64)).to(device))
+            xf = torch.from_numpy(np.fft.fftfreq(n_samples, 1 / sample_rate)).to(device)
+            # np.interp(xf, xp, fp) for every ray at once: end values outside [xp[0], xp[-1]]
+            hi = torch.searchsorted(xp, xf, right=True).clamp(1, xp.numel() - 1)
+            lo = hi - 1
+            w = ((xf - xp[lo]) / (xp[hi] - xp[lo])).clamp(0., 1.)
+            interp = fp[:, lo] + (fp[:, hi] - fp[:, lo]) * w                                     # (n_rays, n_samples)
+            sig_rays = torch.fft.ifft(interp * yf.unsqueeze(0), dim=1).real * 0.01               # simulation.py:474-475
+            out = torch.zeros(n_samples + data_add, dtype=torch.float64, device=device)
+            offsets = np.ceil((T_t - T_target_min) * sample_rate).astype(int)
+            for r in range(sig_rays.shape[0]):                                                   # the reference's order
+                out[int(offsets[r]):int(offsets[r]) + n_samples] += sig_rays[r]
+            return sample_rate, out.cpu().numpy()
+
+        return filter

@@ -33,3 +33,24 @@ def test_scan_and_refine_vs_reference(rt):
         gd = np.array([r.dist_to_target for r in sim.raypacks[f'refine-{it}'].rays])
         assert np.max(np.abs(gd - g[f'refine{it}_dist'])) < 1e-6
     assert abs(sim.dist_avg - float(g['final_dist_avg'])) < 1e-6
+
+
+def test_eigenray_filter_vs_reference(rt):
+    """per-ray target products (Ray2D.gen_filter) and the filtered signal of get_filter_NEW against the
+    reference's own run on a synthetic signal (tests/golden/f5_filter.npz, made by oracle/gen_golden.py f5)."""
+    g = common.load('f5_filter')
+    env = common.product_env(rt, g)
+    sim = rt.EigenraySim2D(env, g['source'], g['target'], int(g['n_rays']), int(g['n_rebounds_max']),
+                           n_rays_scan=int(g['n_rays_scan']), scan_angle_min=float(g['scan_angle_min']),
+                           scan_angle_max=float(g['scan_angle_max']), dx_max=float(g['dx_max']), dz_max=float(g['dz_max']))
+    freqs = [float(f) for f in g['freqs']]
+    angles, T_t, Tm_t = sim.target_products(*freqs)
+    assert np.array_equal(angles, g['angles'])
+    assert np.abs(T_t - g['T_target']).max() < 1e-9
+    ref = g['Tmult_target']
+    assert np.array_equal(Tm_t == 0, ref == 0)                       # underflow at the high frequencies, as in the reference
+    assert (np.abs(Tm_t - ref)[ref != 0] / ref[ref != 0]).max() < 1e-9
+    filt = sim.get_filter_NEW(*freqs)
+    sr, out = filt(float(g['sample_rate']), g['signal'])
+    assert sr == float(g['sample_rate']) and out.shape == g['filtered'].shape
+    assert np.abs(out - g['filtered']).max() < 1e-9 * np.abs(g['filtered']).max()
