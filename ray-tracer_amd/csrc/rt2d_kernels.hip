@@ -1877,7 +1877,10 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     a.geo.inv_rx = 1.0 / res[0]; a.geo.inv_rz = 1.0 / res[1];
     a.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
     a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
-    a.cap = 4096; a.cell_cap = 4096;
+    // LDS per one-ray workgroup: cap * 8 B of hash + cell_cap * 4 B of cached cells; it decides how many rays a CU works on
+    static const int hm_cap = getenv("RT2D_HM_CAP") ? atoi(getenv("RT2D_HM_CAP")) : 4096;
+    static const int hm_cells = getenv("RT2D_HM_CELLS") ? atoi(getenv("RT2D_HM_CELLS")) : 4096;
+    a.cap = hm_cap; a.cell_cap = hm_cells;
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
     // below ~16k rays the latter finishes first
     static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 16384;
