@@ -166,8 +166,9 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     if not one_pass:
         G = torch.empty(total, **f64)
         freq = torch.ones(1, **f64)
+        loss_ws = torch.empty(cap * n, **f64)
         _lib.check(L.rt2d_gain(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap, n,
-                               freq.data_ptr(), 1, total, G.data_ptr(), None, stream))
+                               freq.data_ptr(), 1, total, G.data_ptr(), None, loss_ws.data_ptr(), stream))
     if ev: ev[5].record()
     # plot range of the rays that did not fail (RayPack2D.add fold, origin included) -> heat-map shape
     okm = (status == 0)

@@ -100,7 +100,7 @@ def lib():
                             vp, vp, vp, vp, vp],
         'rt2d_traj_compact': [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
         'rt2d_post': [vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp],
-        'rt2d_gain': [vp, vp, vp, vp, vp, C.POINTER(Rt2dRayOut), i32, i64, vp, i32, i64, vp, vp, vp],
+        'rt2d_gain': [vp, vp, vp, vp, vp, C.POINTER(Rt2dRayOut), i32, i64, vp, i32, i64, vp, vp, vp, vp],
         'rt2d_dist': [vp, vp, vp, vp, i64, C.POINTER(dbl), vp, vp],
         'rt2d_heatmap_accumulate': [vp, vp, vp, vp, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp],
         'rt2d_heatmap_finalize': [vp, C.POINTER(i32), dbl, dbl, vp, vp, vp],

@@ -171,38 +171,36 @@ __device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, dou
 }
 
 // "Last write wins" for a ray whose heat-map column never decreases and whose points all fall inside the map, fed
-// point by point in path order (functions.py:16 semantics without storing the ray): such a ray can only come back to a
-// cell while it is still in the same column, so everything is local to the column it is in -- a register entry for the
-// row it is in, 8 slots per lane (direct-mapped by row & 7, in LDS: slot k of this lane at slot[k * 64]) for rows it has
-// left but may come back to -- and the column is deposited when the ray leaves it.  A ray that breaks a precondition
-// (column decreases, point outside the map, more than 8 rows inside one column) stops being binned and is flagged.
+// point by point in path order (functions.py:16 semantics without storing the ray).  Such a ray can only come back to a
+// cell while it is still in the same column, so the memory it needs is local to that column: 8 slots per lane
+// (direct-mapped by row & 7, in LDS: slot k of this lane at slot[k * 64]).  The value of a cell is deposited the moment
+// the ray LEAVES the cell -- every lane of a wave leaves at most one cell per step, so one run-summed deposit per step
+// serves the whole wave -- and the slot of the row remembers what was deposited; if the ray comes back to the row inside
+// the same column and leaves it again, only the difference to the remembered value is deposited, which leaves the last
+// visit's value in the map (to one rounding).  A ray that breaks a precondition (column decreases, point outside the
+// map, more than 8 rows inside one column) stops being binned and is flagged.
 struct BinTarget { double* H; HeatGeom geo; int32_t nx, nz; double sign; int32_t dbg; };
 
 struct RayBinner {
     int cur_ix, cur_iz, col_lo, col_hi;
-    unsigned occ;                 // slots of the current column that hold a row's last gain
-    double cur_g;
+    unsigned occ;                 // rows (by slot) of the current column whose deposited value is remembered
+    double cur_g;                 // gain of the latest point in the current cell
     bool ok, violated;
     double* slot;
 
-    __device__ __forceinline__ void dep(const BinTarget& t, bool want, int cell, double g, int lane) const {
+    // deposits the cell this lane is leaving (want); stay: the ray stays in the column, so the row must be remembered
+    __device__ __forceinline__ void leave(const BinTarget& t, bool want, bool stay, int lane) {
         if (t.dbg & 2) return;
-        const double v = want ? t.sign * ((t.dbg & 4) ? g : rt2d_heat_val(g)) : 0.0;      // ray.py:317, simulation.py:129
-        if (t.dbg & 1) { if (want) atomicAdd(&t.H[cell], v); }
-        else rt2d_deposit(t.H, want, cell, v, lane);
-    }
-    // deposits the column this lane is leaving (want): register entry first, then the occupied slots
-    __device__ __forceinline__ void flush(const BinTarget& t, bool want, int lane) const {
-        dep(t, want, cur_ix * t.nz + cur_iz, cur_g, lane);
-        unsigned m = want ? occ : 0u;
-        while (__any(m != 0u)) {
-            const bool w = m != 0u;
-            const int k = w ? __ffs(m) - 1 : 0;
-            const int row = col_lo + ((k - col_lo) & 7);
-            const double g = w ? slot[k * RT2D_WAVE] : 0.0;
-            dep(t, w, cur_ix * t.nz + row, g, lane);
-            m &= m - 1u;
+        double v = 0.0, prev = 0.0;
+        const int k = cur_iz & 7;
+        if (want) {
+            v = t.sign * ((t.dbg & 4) ? cur_g : rt2d_heat_val(cur_g));      // ray.py:317, simulation.py:129
+            if (occ & (1u << k)) prev = slot[k * RT2D_WAVE];
+            if (stay) { slot[k * RT2D_WAVE] = v; occ |= 1u << k; }
         }
+        const int cell = cur_ix * t.nz + cur_iz;
+        if (t.dbg & 1) { if (want) atomicAdd(&t.H[cell], v - prev); }
+        else rt2d_deposit(t.H, want, cell, v - prev, lane);
     }
     // first point of the ray (gain g)
     __device__ __forceinline__ void start(const BinTarget& t, bool enabled, double* slot_, double x, double z, double g) {
@@ -219,21 +217,17 @@ struct RayBinner {
         const bool in_map = rt2d_cell_i32(t.geo, x, z, ix, iz) && (unsigned)ix < (unsigned)t.nx && (unsigned)iz < (unsigned)t.nz;
         if (ok && (!in_map || ix < cur_ix)) { ok = false; violated = true; }
         const bool newcol = ok && ix != cur_ix;
-        flush(t, newcol, lane);
-        if (ok) {
-            if (newcol) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; occ = 0u; }
-            else if (iz != cur_iz) {
-                slot[(cur_iz & 7) * RT2D_WAVE] = cur_g;                 // the row the ray leaves keeps its last gain
-                occ |= 1u << (cur_iz & 7);
-                occ &= ~(1u << (iz & 7));                               // an older visit of the row it enters is superseded
-                cur_iz = iz; col_lo = min(col_lo, iz); col_hi = max(col_hi, iz);
-                if (col_hi - col_lo >= 8) { ok = false; violated = true; }
-            }
-            cur_g = g;
+        const bool newrow = ok && !newcol && iz != cur_iz;
+        leave(t, newcol | newrow, newrow, lane);
+        if (newcol) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; occ = 0u; }
+        else if (newrow) {
+            cur_iz = iz; col_lo = min(col_lo, iz); col_hi = max(col_hi, iz);
+            if (col_hi - col_lo >= 8) { ok = false; violated = true; }      // two rows would share a slot
         }
+        if (ok) cur_g = g;
     }
-    // after the last point: the column the ray ends in
-    __device__ __forceinline__ void finish(const BinTarget& t, int lane) const { flush(t, ok, lane); }
+    // after the last point: the cell the ray ends in
+    __device__ __forceinline__ void finish(const BinTarget& t, int lane) { leave(t, ok, false, lane); }
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -839,9 +833,30 @@ struct GainArgs {
     int32_t rebound_cap; int64_t n;
     const double* freqs; int32_t n_freqs; int64_t total;
     double* G; double* G_end;
+    const double* loss;            // optional: rebound losses from rt2d_reb_loss_kernel, [(f * rebound_cap + k) * n + ray]
 };
 
-template <int FCH>
+// Rebound losses 10*log10(refcoef) (ray.py:350-362, model_reflection.py:11-46) of every logged rebound at every
+// frequency, one thread per (ray, rebound).  The sediment coefficient carries a sincos with large-argument reduction, a
+// hypot pair and a log10: evaluated inline in the gain loop they cost that kernel half of its registers (162 against 86)
+// and with them two of five waves per SIMD -- for a few dozen evaluations per ray.  Same expressions, same bits.
+__global__ void __launch_bounds__(256) rt2d_reb_loss_kernel(const GainArgs a, double* loss) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n * a.rebound_cap) return;
+    const int64_t r = idx % a.n;
+    const int k = (int)(idx / a.n);
+    if (k >= min(a.n_rebounds[r], a.rebound_cap)) return;
+    const double fr = a.freqs[blockIdx.y];
+    const double* gtab = a.blob + a.env.gain_off;
+    const int64_t kk = (int64_t)k * a.n + r;
+    const double wavelength = a.reb_velocity[kk] / fr;
+    const double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
+        ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, a.env.imp, a.reb_pos_z[kk], nullptr))
+        : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
+    loss[((int64_t)blockIdx.y * a.rebound_cap + k) * a.n + r] = 10 * log10(rc);
+}
+
+template <int FCH, bool LOSS>
 __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
@@ -903,16 +918,22 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
         double f1s = f1 * f1, f2s = f2 * f2;
         while (s >= next_reb_at) {                                          // ray.py:350-362
             int64_t kk = (int64_t)next_reb * a.n + r;
-            double vel = a.reb_velocity[kk];
-            bool sediment = a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT;
-            double Zp0 = 0.0, ang = 0.0;
-            if (sediment) Zp0 = rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr);
-            else ang = a.reb_angle[kk];
+            if (LOSS) {
 #pragma unroll
-            for (int k = 0; k < FCH; ++k) {
-                double wavelength = vel / fr[k];
-                double rc = sediment ? rt2d_refcoef_sediment(wavelength, Zp0) : rt2d_refcoef_surface(wavelength, ang);
-                A[k] += 10 * log10(rc);
+                for (int k = 0; k < FCH; ++k)
+                    if (k < nf) A[k] += a.loss[((int64_t)(f0 + k) * a.rebound_cap + next_reb) * a.n + r];
+            } else {
+                double vel = a.reb_velocity[kk];
+                bool sediment = a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT;
+                double Zp0 = 0.0, ang = 0.0;
+                if (sediment) Zp0 = rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr);
+                else ang = a.reb_angle[kk];
+#pragma unroll
+                for (int k = 0; k < FCH; ++k) {
+                    double wavelength = vel / fr[k];
+                    double rc = sediment ? rt2d_refcoef_sediment(wavelength, Zp0) : rt2d_refcoef_surface(wavelength, ang);
+                    A[k] += 10 * log10(rc);
+                }
             }
             ++next_reb;
             next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
@@ -1779,7 +1800,7 @@ int32_t rt2d_post(rt2d_env_t env, const double* X, const double* Z, const int64_
 
 int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                   const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, const double* freqs, int32_t n_freqs,
-                  int64_t total, double* G, double* G_end, void* stream) {
+                  int64_t total, double* G, double* G_end, double* loss_ws, void* stream) {
     if (!env || !X || !Z || !tile_off || !n_pts || !reb || !freqs) return fail("rt2d_gain: null argument");
     if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
         return fail("rt2d_gain: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
@@ -1811,8 +1832,19 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     }
     const int block = (n <= 64 * 512) ? 64 : 256;
     dim3 grid((unsigned)((n + block - 1) / block), (unsigned)((n_freqs + fch - 1) / fch));
-    void (*kern)(const GainArgs) = fch == 8 ? rt2d_gain_kernel<8> : fch == 4 ? rt2d_gain_kernel<4>
-                                  : fch == 2 ? rt2d_gain_kernel<2> : rt2d_gain_kernel<1>;
+    void (*kern)(const GainArgs);
+    if (loss_ws && rebound_cap > 0) {
+        // rebound losses first, one thread per (ray, rebound, frequency); the gain loop then only reads them
+        const int64_t pairs = n * rebound_cap;
+        hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)n_freqs), dim3(256), 0,
+                           (hipStream_t)stream, a, loss_ws);
+        a.loss = loss_ws;
+        kern = fch == 8 ? rt2d_gain_kernel<8, true> : fch == 4 ? rt2d_gain_kernel<4, true>
+             : fch == 2 ? rt2d_gain_kernel<2, true> : rt2d_gain_kernel<1, true>;
+    } else {
+        kern = fch == 8 ? rt2d_gain_kernel<8, false> : fch == 4 ? rt2d_gain_kernel<4, false>
+             : fch == 2 ? rt2d_gain_kernel<2, false> : rt2d_gain_kernel<1, false>;
+    }
     HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());

@@ -29,6 +29,7 @@ SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below
 # (SPECULATIVE_ROOM points of room per ray) that is then kept as the fan's layout -- untouched pages cost nothing -- as
 # long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
 PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
+LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
 
 
 def _torch():
@@ -384,10 +385,13 @@ class RayFan:
             fr = torch.tensor([float(f) for f in new], **f64)
             G = torch.empty((len(new), self.total), **f64) if keep_arrays else None
             G_end = torch.empty((len(new), self.n), **f64)
+            # workspace for the rebound losses (their own kernel, see rt2d_gain) while it stays modest
+            ws_elems = len(new) * self.rebound_cap * self.n
+            loss_ws = torch.empty(ws_elems, **f64) if 0 < ws_elems * 8 <= LOSS_WS_BYTES else None
             _lib.check(L.rt2d_gain(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
                                    self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out),
                                    self.rebound_cap, self.n, fr.data_ptr(), len(new), self.total, _ptr(G),
-                                   G_end.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                   G_end.data_ptr(), _ptr(loss_ws), torch.cuda.current_stream().cuda_stream))
         for k, f in enumerate(new):
             if G is not None:
                 self.G[f] = G[k]

@@ -249,11 +249,18 @@ def test_gain_two_phase_equals_one_pass(rt, monkeypatch):
     monkeypatch.setenv('RT2D_GAIN_TWO_PHASE_MAX_RAYS', '0')
     fan1, _ = _cast(rt, g)
     fan1.populate(*freqs)
-    for f in freqs:
-        assert np.array_equal(fan.G_end[f].cpu().numpy(), fan1.G_end[f].cpu().numpy(), equal_nan=True)
-        for i in range(0, fan.n, 37):
-            a, b = fan.ray_slice(fan.G[f], i).cpu().numpy(), fan1.ray_slice(fan1.G[f], i).cpu().numpy()
-            assert np.array_equal(a, b, equal_nan=True)
+    # ... and the one-pass kernel with the rebound losses evaluated inside its loop (no workspace) instead of by their
+    # own kernel
+    from ray_tracer_amd import rays
+    monkeypatch.setattr(rays, 'LOSS_WS_BYTES', 0)
+    fan2, _ = _cast(rt, g)
+    fan2.populate(*freqs)
+    for other in (fan1, fan2):
+        for f in freqs:
+            assert np.array_equal(fan.G_end[f].cpu().numpy(), other.G_end[f].cpu().numpy(), equal_nan=True)
+            for i in range(0, fan.n, 37):
+                a, b = fan.ray_slice(fan.G[f], i).cpu().numpy(), other.ray_slice(other.G[f], i).cpu().numpy()
+                assert np.array_equal(a, b, equal_nan=True)
 
 
 def test_heatmaps_for_an_array_of_frequencies(rt, orc):
