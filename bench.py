@@ -197,7 +197,7 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         viol = torch.zeros(1, dtype=torch.int64, device=device)
         _lib.check(L.rt2d_gain_heatmap(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap,
                                        n, 1.0, mask.data_ptr(), res_c, shape_c, H.data_ptr(), G.data_ptr() if n_rest else None,
-                                       None, None, viol.data_ptr(), stream))
+                                       None, None, viol.data_ptr(), torch.empty(cap * n, **f64).data_ptr(), stream))
         if n_rest:
             _lib.check(L.rt2d_heatmap_accumulate(X.data_ptr(), Z.data_ptr(), G.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), n,
                                                  rest.to(torch.uint8).data_ptr(), res_c, shape_c, H.data_ptr(), None, None, stream))

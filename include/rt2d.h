@@ -180,12 +180,22 @@ int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const d
  * monotone, slope_max (may be NULL).  irregular (device, n bytes, may be NULL) / n_violations (device int64, may be
  * NULL, caller zeroes it): a ray that breaks the precondition stops being binned, is flagged and counted -- with a
  * ray_mask built as above the count is 0; otherwise H is not the reference's map.
+ * loss / loss_cap: optional (NULL, 0): the rebound losses at `freq` of these same rays from rt2d_rebound_loss over the
+ * rebound log of the prior cast, entry k of ray r at [k*n + r], k < loss_cap.  The propagation is deterministic, so the
+ * k-th rebound met here is the k-th logged one; the kernel then carries no reflection-coefficient code (sincos, hypot,
+ * log10) and needs a third fewer registers.  Same map.
  * Fails (<0) when the sound-speed, floor, surface and absorption tables do not fit in LDS together. */
 int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const double* src,
                           const Rt2dParams* params, const double* init_slope, const double* init_mult,
                           const uint8_t* ray_mask, double freq, const int32_t* res, const int32_t* shape,
                           double sign, double* H, const Rt2dRayOut* out, uint8_t* irregular,
-                          int64_t* n_violations, void* stream);
+                          int64_t* n_violations, const double* loss, int32_t loss_cap, void* stream);
+
+/* Rebound losses 10*log10(reflection coefficient) of every logged rebound at F frequencies (reference: ray.py:350-362,
+ * model_reflection.py:11-46), one thread per (ray, rebound, frequency).  loss: device, F * rebound_cap * n doubles,
+ * entry k of ray r at frequency f at [(f*rebound_cap + k)*n + r]; entries k >= n_rebounds[r] are left untouched. */
+int32_t rt2d_rebound_loss(rt2d_env_t env, const Rt2dRayOut* rebounds, int32_t rebound_cap, int64_t n,
+                          const double* freqs, int32_t n_freqs, double* loss, void* stream);
 
 /* Copies trajectories from one tile layout to another (typically provisional -> exact); the first
  * tile_off_dst[t+1]-tile_off_dst[t] elements of every tile are copied.  C_src/C_dst may both be NULL.
@@ -219,12 +229,13 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
  * (x never decreases, every point inside the map, at most 8 rows per column).  2 = only compute the ray's gain and
  * store it to G (device, tile layout, `total` elements as for rt2d_gain; may be NULL when no ray has mask 2): the caller
  * then bins these rays with rt2d_heatmap_accumulate.  0 = skip.  G_end (device, n, may be NULL): gain at the last point.
- * irregular / n_violations: as for rt2d_cast_heatmap. */
+ * irregular / n_violations: as for rt2d_cast_heatmap.
+ * loss_ws: optional device workspace of rebound_cap * n doubles for the rebound losses (as for rt2d_gain). */
 int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off,
                           const int32_t* n_pts, const Rt2dRayOut* rebounds, int32_t rebound_cap, int64_t n,
                           double freq, const uint8_t* ray_mask, const int32_t* res, const int32_t* shape,
                           double* H, double* G, double* G_end, uint8_t* irregular, int64_t* n_violations,
-                          void* stream);
+                          double* loss_ws, void* stream);
 
 /* Distance to a target from stored trajectories (reference: ray.py:282-287). dist: device, n. */
 int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,

@@ -256,6 +256,8 @@ struct CastArgs {
     unsigned long long* n_violations;
     int32_t fuse_step_doubles;    // blob prefix staged in LDS: sound speed, floor, surface (slopes are read from global)
     int32_t fuse_abs_doubles;     // length of the absorption table staged behind it
+    const double* fuse_loss;      // FUSE == 2: rebound losses of a previous cast of the same rays, [k * n + ray]
+    int32_t fuse_loss_cap;        // ... k < fuse_loss_cap
 };                                // bin.dbg: experiments (RT2D_FUSE_DBG): 1 = no cross-lane aggregation, 2 = no deposit, 4 = no exp2
 
 // RN(a / b) for a divisor b > 0 whose correctly rounded reciprocal y = RN(1/b) is known (Markstein's correction
@@ -406,8 +408,12 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 // the ray leaves it.  Slope tables and the impedance table are read from global memory (rebounds only) to make room.
 #define RT2D_FUSE_MAX_WAVES 8      // launch bound of the FUSE kernels: they want ~250 vector registers; at 12 waves (168
                                    // registers) the spills cost more than the lost occupancy (27 vs 22 ms per 1M rays)
-template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC, bool FUSE = false>
-__global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
+#ifndef RT2D_FUSE2_MAX_WAVES
+#define RT2D_FUSE2_MAX_WAVES 8     // with the rebound losses precomputed (FUSE == 2): 216 registers; at 12 waves (168, ~30 words
+                                   // spilled) the step itself is faster (10.7 vs 12.0 ms per 1M rays) but the deposits twice as slow
+#endif
+template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC, int FUSE = 0>
+__global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE : FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
     CastCold* cold = reinterpret_cast<CastCold*>(s_mem);
@@ -621,7 +627,9 @@ __global__ void __launch_bounds__(FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024)
                     status = RT2D_RAY_ERR_REBOUND_LOG;
                 }
                 n_reb += 1;
-                if (CUTOFF || FUSE) {                                           // ray.py:350-362; applies from the NEXT point on
+                if (FUSE == 2) {                                                // the k-th rebound's loss, computed beforehand
+                    g_pend = (n_reb <= a.fuse_loss_cap) ? a.fuse_loss[(int64_t)(n_reb - 1) * cold->n + r] : 0.0;
+                } else if (CUTOFF || FUSE) {                                    // ray.py:350-362; applies from the NEXT point on
                     double wavelength = c / g_freq;
                     double rc = hit_floor ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, e.imp, z, nullptr))
                                           : rt2d_refcoef_surface(wavelength, ang);
@@ -840,13 +848,13 @@ struct GainArgs {
 // frequency, one thread per (ray, rebound).  The sediment coefficient carries a sincos with large-argument reduction, a
 // hypot pair and a log10: evaluated inline in the gain loop they cost that kernel half of its registers (162 against 86)
 // and with them two of five waves per SIMD -- for a few dozen evaluations per ray.  Same expressions, same bits.
-__global__ void __launch_bounds__(256) rt2d_reb_loss_kernel(const GainArgs a, double* loss) {
+__global__ void __launch_bounds__(256) rt2d_reb_loss_kernel(const GainArgs a, double* loss, double one_freq) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n * a.rebound_cap) return;
     const int64_t r = idx % a.n;
     const int k = (int)(idx / a.n);
     if (k >= min(a.n_rebounds[r], a.rebound_cap)) return;
-    const double fr = a.freqs[blockIdx.y];
+    const double fr = a.freqs ? a.freqs[blockIdx.y] : one_freq;       // a single frequency may come by value
     const double* gtab = a.blob + a.env.gain_off;
     const int64_t kk = (int64_t)k * a.n + r;
     const double wavelength = a.reb_velocity[kk] / fr;
@@ -1122,6 +1130,7 @@ struct GainHeatArgs {
     const uint8_t* ray_mask; uint8_t* irregular; unsigned long long* n_violations;
 };
 
+template <bool LOSS>
 __global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatArgs b) {
     const GainArgs& a = b.g;
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
@@ -1160,11 +1169,15 @@ __global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatAr
         rt2d_lookup<19>(tab, ab, zp, rec);                                  // factors at the START of the segment, ray.py:346
         while (s >= next_reb_at) {                                          // ray.py:350-362
             int64_t kk = (int64_t)next_reb * a.n + r;
-            double wavelength = a.reb_velocity[kk] / fr;
-            double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
-                ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr))
-                : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
-            A += 10 * log10(rc);
+            if (LOSS) {
+                A += a.loss[kk];
+            } else {
+                double wavelength = a.reb_velocity[kk] / fr;
+                double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
+                    ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(tab, a.env.imp, a.reb_pos_z[kk], nullptr))
+                    : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
+                A += 10 * log10(rc);
+            }
             ++next_reb;
             next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
         }
@@ -1701,7 +1714,7 @@ int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const d
 int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* params,
                           const double* init_slope, const double* init_mult, const uint8_t* ray_mask, double freq,
                           const int32_t* res, const int32_t* shape, double sign, double* H, const Rt2dRayOut* out,
-                          uint8_t* irregular, int64_t* n_violations, void* stream) {
+                          uint8_t* irregular, int64_t* n_violations, const double* loss, int32_t loss_cap, void* stream) {
     Rt2dRayOut none; memset(&none, 0, sizeof none);
     if (!out) out = &none;
     int32_t rc = check_cast(env, angles, n, src, params, init_slope, init_mult, out);
@@ -1732,14 +1745,16 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
         return fail("rt2d_cast_heatmap: the sound-speed, floor, surface and absorption tables (%zu bytes) leave no room in LDS; "
                     "use rt2d_cast_write + rt2d_gain + rt2d_heatmap_accumulate", tab_bytes);
     int waves = (int)((RT2D_LDS_BUDGET - cold - tab_bytes) / per_wave);
-    if (waves > RT2D_FUSE_MAX_WAVES) waves = RT2D_FUSE_MAX_WAVES;
+    if (waves > (loss ? RT2D_FUSE2_MAX_WAVES : RT2D_FUSE_MAX_WAVES)) waves = loss ? RT2D_FUSE2_MAX_WAVES : RT2D_FUSE_MAX_WAVES;
     static const int waves_env = getenv("RT2D_FUSE_WAVES") ? atoi(getenv("RT2D_FUSE_WAVES")) : 0;
     if (waves_env > 0 && waves_env < waves) waves = waves_env;
     const int block = waves * RT2D_WAVE;
     const size_t lds = cold + tab_bytes + (size_t)waves * per_wave;
     const int64_t grid = (n + block - 1) / block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
-    auto k = env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, true> : rt2d_cast_kernel<false, true, 1, false, false, true>;
+    a.fuse_loss = loss; a.fuse_loss_cap = loss ? loss_cap : 0;
+    auto k = loss ? (env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, 2> : rt2d_cast_kernel<false, true, 1, false, false, 2>)
+                  : (env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, 1> : rt2d_cast_kernel<false, true, 1, false, false, 1>);
     HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
@@ -1798,6 +1813,25 @@ int32_t rt2d_post(rt2d_env_t env, const double* X, const double* Z, const int64_
     return 0;
 }
 
+int32_t rt2d_rebound_loss(rt2d_env_t env, const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, const double* freqs,
+                          int32_t n_freqs, double* loss, void* stream) {
+    if (!env || !reb || !freqs || !loss) return fail("rt2d_rebound_loss: null argument");
+    if (!reb->n_rebounds || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
+        return fail("rt2d_rebound_loss: the rebound log (n_rebounds, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
+    if (n < 0 || n_freqs < 0 || rebound_cap < 0) return fail("rt2d_rebound_loss: negative count");
+    if (n == 0 || n_freqs == 0 || rebound_cap == 0) return 0;
+    GainArgs a; memset(&a, 0, sizeof a);
+    a.env = env->dev; a.blob = env->blob;
+    a.n_rebounds = reb->n_rebounds; a.reb_surface = reb->reb_surface;
+    a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
+    a.rebound_cap = rebound_cap; a.n = n; a.freqs = freqs; a.n_freqs = n_freqs;
+    const int64_t pairs = n * rebound_cap;
+    hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)n_freqs), dim3(256), 0,
+                       (hipStream_t)stream, a, loss, 0.0);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                   const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, const double* freqs, int32_t n_freqs,
                   int64_t total, double* G, double* G_end, double* loss_ws, void* stream) {
@@ -1837,7 +1871,7 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
         // rebound losses first, one thread per (ray, rebound, frequency); the gain loop then only reads them
         const int64_t pairs = n * rebound_cap;
         hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)n_freqs), dim3(256), 0,
-                           (hipStream_t)stream, a, loss_ws);
+                           (hipStream_t)stream, a, loss_ws, 0.0);
         a.loss = loss_ws;
         kern = fch == 8 ? rt2d_gain_kernel<8, true> : fch == 4 ? rt2d_gain_kernel<4, true>
              : fch == 2 ? rt2d_gain_kernel<2, true> : rt2d_gain_kernel<1, true>;
@@ -1855,7 +1889,7 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
 int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                           const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                           const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,
-                          uint8_t* irregular, int64_t* n_violations, void* stream) {
+                          uint8_t* irregular, int64_t* n_violations, double* loss_ws, void* stream) {
     if (!env || !X || !Z || !tile_off || !n_pts || !reb || !res || !shape || !H) return fail("rt2d_gain_heatmap: null argument");
     if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
         return fail("rt2d_gain_heatmap: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
@@ -1875,8 +1909,15 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
     const int block = (n <= 64 * 512) ? 64 : 512;
     const size_t lds = ((size_t)env->dev.gain_doubles + (size_t)(block / RT2D_WAVE) * 8 * RT2D_WAVE) * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain_heatmap: absorption tables do not fit in LDS");
-    HIP_OK(hipFuncSetAttribute((const void*)rt2d_gain_heatmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(rt2d_gain_heatmap_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
+    void (*kern)(const GainHeatArgs) = rt2d_gain_heatmap_kernel<false>;
+    if (loss_ws && rebound_cap > 0) {
+        const int64_t pairs = n * rebound_cap;
+        hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, (hipStream_t)stream, a, loss_ws, freq);
+        a.loss = loss_ws;
+        kern = rt2d_gain_heatmap_kernel<true>;
+    }
+    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
     HIP_OK(hipGetLastError());
     return 0;
 }

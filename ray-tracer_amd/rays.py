@@ -60,6 +60,7 @@ class RayFan:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.kw = {k: kwargs.get(k, v) for k, v in self.PROPAGATE_DEFAULTS.items()}
         self.store = bool(store)
+        self.keep_log = bool(kwargs.get('keep_log', True))      # store=False: keep the rebound log for the fused heat map
         if torch.is_tensor(angles):
             self.angles_dev = angles.to(device=self.device, dtype=torch.float64).contiguous()
             self._angles_host = None
@@ -88,6 +89,7 @@ class RayFan:
 
     def _cast(self, init, store_c):
         torch = _torch()
+        kwargs_keep_log = self.keep_log
         L = _lib.lib()
         n, dev = self.n, self.device
         with torch.cuda.device(dev):
@@ -153,10 +155,16 @@ class RayFan:
             if n == 0:
                 return
             if not self.store:
-                # scalars only: one pass with the post-pass folded in
-                p = self._params(0)
+                # scalars only: one pass with the post-pass folded in.  With a bounded rebound count the rebound log is kept
+                # too (37 B per rebound): the fused heat-map kernel reads its rebound losses from it (heatmap_accumulate_fused)
+                out = full_out()
+                nrm = int(self.kw['n_rebounds_max'])
+                if nrm > -1 and kwargs_keep_log:
+                    alloc_log(out, nrm + 1)
+                p = self._params(self.rebound_cap)
                 _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
-                                             _ptr(init_mult), C.byref(full_out()), stream))
+                                             _ptr(init_mult), C.byref(out), stream))
+                self._out = out
                 return
             n_tiles = (n + TILE - 1) // TILE
             self.tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
@@ -448,10 +456,18 @@ class RayFan:
             src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
             p = self._params(0)
             viol = torch.zeros(1, dtype=torch.int64, device=self.device)
-            _lib.check(L.rt2d_cast_heatmap(self.env.device_handle(self.device.index), self.angles_dev.data_ptr(), self.n, src,
+            handle = self.env.device_handle(self.device.index)
+            stream = torch.cuda.current_stream().cuda_stream
+            loss, cap = None, 0
+            if self.rebound_cap > 0 and self.rebound_cap * self.n * 8 <= LOSS_WS_BYTES:
+                # the rebound losses at this frequency from the count pass's log, by their own kernel (rt2d_rebound_loss)
+                cap = self.rebound_cap
+                loss = torch.empty(cap * self.n, dtype=torch.float64, device=self.device)
+                fr = torch.tensor([float(freq)], dtype=torch.float64, device=self.device)
+                _lib.check(L.rt2d_rebound_loss(handle, C.byref(self._out), cap, self.n, fr.data_ptr(), 1, loss.data_ptr(), stream))
+            _lib.check(L.rt2d_cast_heatmap(handle, self.angles_dev.data_ptr(), self.n, src,
                                            C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
-                                           res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(),
-                                           torch.cuda.current_stream().cuda_stream))
+                                           res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(), _ptr(loss), cap, stream))
             rest = torch.nonzero(sel & (mask == 0)).flatten()
             self.last_slow_rays = int(rest.numel())
             self.last_fused_violations = viol
@@ -480,10 +496,12 @@ class RayFan:
             viol = torch.zeros(1, dtype=torch.int64, device=self.device)
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+            ws_elems = self.rebound_cap * self.n
+            loss_ws = torch.empty(ws_elems, dtype=torch.float64, device=self.device) if 0 < ws_elems * 8 <= LOSS_WS_BYTES else None
             _lib.check(L.rt2d_gain_heatmap(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
                                            self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap,
                                            self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(), _ptr(G), None, None,
-                                           viol.data_ptr(), stream))
+                                           viol.data_ptr(), _ptr(loss_ws), stream))
             if n_rest:
                 _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), G.data_ptr(), self.tile_off.data_ptr(),
                                                      self.n_pts.data_ptr(), self.n, rest.to(torch.uint8).data_ptr(), res_c, shape_c,

@@ -83,6 +83,6 @@ def test_fused_kernel_flags_a_ray_it_cannot_bin(rt):
     p = fan._params(0)
     _lib.check(_lib.lib().rt2d_cast_heatmap(env.device_handle(0), fan.angles_dev.data_ptr(), fan.n, src, C.byref(p), None, None,
                                            None, 1.0, (C.c_int32 * 2)(50, 25), (C.c_int32 * 2)(*shape), 1.0, H.data_ptr(), None,
-                                           irr.data_ptr(), viol.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                           irr.data_ptr(), viol.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream))
     assert int(viol.item()) == int(irr.sum().item()) >= n_back
     assert bool((irr[(fan.monotone == 0) & (fan.status == 0)] == 1).all().item())
