@@ -1234,7 +1234,9 @@ struct HeatArgs {
 // row) pair is seen -- a per-lane bit mask of the rows seen in the current column, no hash.  Rays that fail the
 // forward check (backward-moving rays, points outside the map, which would alias flat indices) are queued for the
 // general kernel below.
-#define HM_UNROLL 4
+#ifndef HM_UNROLL
+#define HM_UNROLL 4      // measured: 8 rows in flight cost registers and 1.7 ms per 1M rays
+#endif
 template <int MW>     // 64-bit mask words per lane: rows nz <= 64 * MW
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
     const int64_t tile = (int64_t)blockIdx.x * (blockDim.x / RT2D_WAVE) + (threadIdx.x / RT2D_WAVE);

@@ -29,6 +29,7 @@ SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below
 # (SPECULATIVE_ROOM points of room per ray) that is then kept as the fan's layout -- untouched pages cost nothing -- as
 # long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
 PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
+SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat map hands rays to the stored path
 LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
 
 
@@ -465,18 +466,24 @@ class RayFan:
                 loss = torch.empty(cap * self.n, dtype=torch.float64, device=self.device)
                 fr = torch.tensor([float(freq)], dtype=torch.float64, device=self.device)
                 _lib.check(L.rt2d_rebound_loss(handle, C.byref(self._out), cap, self.n, fr.data_ptr(), 1, loss.data_ptr(), stream))
-            _lib.check(L.rt2d_cast_heatmap(handle, self.angles_dev.data_ptr(), self.n, src,
-                                           C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
-                                           res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(), _ptr(loss), cap, stream))
+            rc = L.rt2d_cast_heatmap(handle, self.angles_dev.data_ptr(), self.n, src,
+                                     C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
+                                     res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(), _ptr(loss), cap, stream)
+            if rc != 0:
+                # the fused kernel cannot take this environment (its tables do not fit in LDS) or these parameters
+                # (power_cutoff): every ray goes through the stored path, a chunk at a time
+                self.fused_unavailable = L.rt2d_last_error().decode()
+                mask = torch.zeros_like(mask)
             rest = torch.nonzero(sel & (mask == 0)).flatten()
             self.last_slow_rays = int(rest.numel())
             self.last_fused_violations = viol
-            if rest.numel():
-                init = None if self._init[0] is None else (self._init[0][rest].cpu().numpy(), self._init[1][rest].cpu().numpy())
-                kw = dict(self.kw)
-                side = RayFan(self.env, self.source, self.angles_dev[rest], target=None, store=True, device=self.device,
-                              init=init, **kw)
-                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=False)   # none of them suits the tile kernel
+            for c0 in range(0, int(rest.numel()), SIDE_FAN_RAYS):
+                part = rest[c0:c0 + SIDE_FAN_RAYS]
+                init = None if self._init[0] is None else (self._init[0][part].cpu().numpy(), self._init[1][part].cpu().numpy())
+                side = RayFan(self.env, self.source, self.angles_dev[part], target=None, store=True, device=self.device,
+                              init=init, **dict(self.kw))
+                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=rc != 0)
+                del side
 
     def heatmap_accumulate_stream(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
         """Gain and binning in ONE forward pass over the stored trajectories (rt2d_gain_heatmap): the gain array is never

@@ -86,3 +86,27 @@ def test_fused_kernel_flags_a_ray_it_cannot_bin(rt):
                                            irr.data_ptr(), viol.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream))
     assert int(viol.item()) == int(irr.sum().item()) >= n_back
     assert bool((irr[(fan.monotone == 0) & (fan.status == 0)] == 1).all().item())
+
+
+def test_fused_at_default_resolution(rt):
+    """dx_max = 10, dz_max = 0.1 (preferences.py:6-7): up to 100 001 points per ray, the case the fused kernel exists for
+    (a stored 1 M-ray fan would need 1.6 TB).  64 rays on the c2 environment, fused against stored."""
+    g = common.load('c2_fan999')
+    angles = np.linspace(-1.2, -0.05, 64)
+    Hs, Hf, fan, _, _ = _maps(rt, g, angles=angles, res=(50, 25), dx_max=10., dz_max=.1, n_rebounds_max=-1)
+    assert int(fan.n_pts.max().item()) > 50000
+    assert int(fan.last_fused_violations.item()) == 0
+    print(f'default resolution: {fan.ray_steps()} ray-steps, {fan.last_slow_rays} of {fan.n} rays through the stored path')
+    assert np.array_equal(Hf == 0, Hs == 0)
+    assert (np.abs(Hf - Hs)[Hs != 0] / Hs[Hs != 0]).max() < 1e-12
+
+
+def test_fused_falls_back_when_the_tables_do_not_fit(rt):
+    """The tests_2.ipynb environment (5 km deep, 4001 floor samples) has 200 KB of tables: the fused kernel declines and
+    heatmap() on a store=False fan bins every ray through the stored path instead -- same map."""
+    g = common.load('t2_single')
+    angles = np.linspace(-1.0, -0.1, 50)
+    Hs, Hf, fan, _, _ = _maps(rt, g, angles=angles, dx_max=50., dz_max=25., n_rebounds_max=6)
+    assert 'LDS' in fan.fused_unavailable and fan.last_slow_rays == int((fan.status == 0).sum().item())
+    assert np.array_equal(Hf == 0, Hs == 0)
+    assert (np.abs(Hf - Hs)[Hs != 0] / Hs[Hs != 0]).max() < 1e-12
