@@ -571,7 +571,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
             margin = fmin(margin, fmin(fabs(z_new - z_floor), fabs(z_new - z_ceil)));
         }
         bool final_pt = false;                 // the point about to be accepted is the ray's last (max-rebounds)
-        if (general) {
+        // (branch hints: a wave alone on its CU pays an instruction-fetch stall at every taken branch, so the common
+        // step should be laid out as straight-line code)
+        if (__builtin_expect(general, 0)) {
             if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
             // clipped in x is still inside in z; the clipped point is NOT appended
@@ -682,20 +684,20 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
             min_z = fmin(min_z, z); max_z = fmax(max_z, z);
         }
         if (FULL && has_target) tt.add(x, z, T, n_pts, tx);
-        if (WRITE && n_pts < room) {
+        if (WRITE && __builtin_expect(n_pts < room, 1)) {
             px += RT2D_WAVE; pz += RT2D_WAVE;
             *px = x; *pz = z;
             if (pc) { pc += RT2D_WAVE; *pc = c; }
         }
         n_pts += 1;
         if (FUSE) binner.point(a.bin, x, z, g_pt, lane);
-        if (final_pt) break;
+        if (__builtin_expect(final_pt, 0)) break;
         if (CUTOFF && cut) { stop = RT2D_STOP_POWER_CUTOFF; break; }
         x_dir = rt2d_sign(kx);
         // k1/k0 (ray.py:243).  In a wave whose rays all took a plain dx_max step, k0 is +-dx_max exactly and the quotient
         // comes from rt2d_div_by_const (same bits); any other wave divides.
         const bool plain = !steep & !general & (fabs(kx) == p.dx_max) & (fabs(kz) >= 1e-250);
-        if (__all(plain)) {
+        if (__builtin_expect(__all(plain), 1)) {
             const double q = rt2d_div_by_const(kz, p.dx_max, a.inv_dx_max);
             dx_z = (kx < 0.0) ? -1 * q : q;
         } else {
@@ -705,7 +707,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         dx_z += dxdx_z * kx;
         kx = x_dir; kz = dx_z;
 
-        if (!p.backprop && x_dir < 0) { stop = RT2D_STOP_BACKPROP; break; }   // ray.py:252-255
+        if (__builtin_expect(!p.backprop && x_dir < 0, 0)) { stop = RT2D_STOP_BACKPROP; break; }   // ray.py:252-255
         if (i == p.n_steps_max - 1) stop = RT2D_STOP_MAX_ITER;                 // ray.py:257-259
     }
 

@@ -1,0 +1,65 @@
+"""GPU: randomised parity.  Seeded random environments (sea floors with relief, flat or rippled surfaces), sources,
+targets and propagation parameters; the HIP kernels against the oracle reading the SAME tables and start values: every
+integer and every stored double must be identical.  This is the net under the fast paths of the stepping kernel (constant
+surface instance, skipped step division, two-FMA quotient, one-predicate common step), which only exist because they are
+claimed to change no bit."""
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(rt, rng):
+    length = float(rng.choice([8000., 20000., 60000.]))
+    depth = float(rng.uniform(300., 3000.))
+    nx = int(rng.integers(40, 400))
+    xs = np.linspace(0., length, nx)
+    relief = rng.uniform(0., 0.35) * depth
+    floor = -depth + relief * np.sin(xs / rng.uniform(500., 5000.) + rng.uniform(0, 6.28)) * rng.uniform(0.2, 1.) \
+        + rng.normal(scale=rng.uniform(0., 3.), size=nx)
+    if rng.random() < 0.5:
+        ceil_x, ceil_z = np.array([0., length]), np.array([0., 0.])                     # flat sea surface (CEILC kernels)
+    else:
+        ceil_x = np.linspace(0., length, int(rng.integers(20, 200)))
+        ceil_z = -1.0 + rng.uniform(0.1, 1.) * np.cos(ceil_x / rng.uniform(50., 800.))  # swell (general kernels)
+    zmin = float(np.floor(floor.min())) - 1.
+    env = rt.Environment2D((xs, floor), (ceil_x, ceil_z), np.array([0., zmin]), np.array([length, 1.]),
+                           res_x=int(rng.choice([50, 100, 200])), res_z=int(rng.choice([5, 10, 20])))
+    source = np.array([float(rng.uniform(0., 0.2 * length)), float(rng.uniform(0.9 * floor.max(), -2.))])
+    kw = dict(dx_max=float(rng.choice([10., 25., 50., 80.])), dz_max=float(rng.choice([0.5, 5., 25., 40.])),
+              n_rebounds_max=int(rng.choice([-1, 0, 3, 12])), backprop=bool(rng.random() < 0.7),
+              n_steps_max=int(rng.choice([300, 3000, 100000])))
+    target = np.array([float(rng.uniform(0.3, 0.9) * length), float(rng.uniform(0.8 * floor.max(), -5.))]) if rng.random() < 0.5 else None
+    angles = np.sort(rng.uniform(-1.3, 1.3, 48))
+    angles[0] = 0.0                                                                      # a horizontal launch: slope exactly 0
+    return env, source, target, angles, kw
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_environment_bit_exact(rt, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    env, source, target, angles, kw = _random_case(rt, rng)
+    oenv = common.oracle_env_from_product(orc, env)
+    init = common.host_init(float(env.penv.calc_c(0.)), angles)
+    fan = rt.RayFan(env, source, angles, target=target, init=init, **kw)
+    p = orc.make_params(target=target, **kw)
+    rays = [orc.cast_ray(oenv, source, a, p, init=(init[0][i], init[1][i])) for i, a in enumerate(angles)]
+    assert np.array_equal(fan.host('status'), [r.status for r in rays])
+    assert np.array_equal(fan.host('n_pts'), [r.steps for r in rays])
+    assert np.array_equal(fan.host('stop_code'), [r.stop_code for r in rays])
+    assert np.array_equal(fan.host('n_rebounds'), [r.n_rebounds for r in rays])
+    assert np.array_equal(fan.host('T_end'), [r.T[-1] for r in rays])
+    assert np.array_equal(fan.host('margin'), [r.margin for r in rays])
+    if target is not None:
+        np.testing.assert_array_equal(fan.host('dist'), [r.dist_to_target for r in rays])
+    for i, r in enumerate(rays):
+        assert np.array_equal(rt.Ray2D._from_fan(fan, i).XZ, r.XZ), f'seed {seed} ray {i}'
+        nl = min(len(r.reb_step), fan.rebound_cap)
+        assert np.array_equal(fan.host('reb_step')[:nl, i], r.reb_step[:nl])
+        assert np.array_equal(fan.host('reb_angle')[:nl, i], r.reb_angle[:nl])
+    stops = sorted(set(fan.host('stop_code').tolist()))
+    print(f'seed {seed}: stop codes {stops}, {int(fan.host("n_rebounds").sum())} rebounds, {fan.ray_steps()} ray-steps, '
+          f'{int((fan.host("status") != 0).sum())} ray errors, kw {kw}')
