@@ -63,3 +63,28 @@ def test_random_environment_bit_exact(rt, orc, seed):
     stops = sorted(set(fan.host('stop_code').tolist()))
     print(f'seed {seed}: stop codes {stops}, {int(fan.host("n_rebounds").sum())} rebounds, {fan.ray_steps()} ray-steps, '
           f'{int((fan.host("status") != 0).sum())} ray errors, kw {kw}')
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_environment_heat_maps_agree(rt, seed):
+    """The three ways to a heat map -- stored trajectories + gain + binning kernels, one pass over stored trajectories,
+    fused cast+gain+binning -- on random environments, cell sizes and frequencies: same map to 1e-12."""
+    rng = np.random.default_rng(2000 + seed)
+    env, source, target, angles, kw = _random_case(rt, rng)
+    kw['n_steps_max'] = min(kw['n_steps_max'], 3000)
+    res = [int(v) for v in rng.choice([[50, 25], [20, 10], [100, 50], [10, 5]])]
+    freq = float(rng.choice([1., 200., 3000.]))
+    sims = {}
+    for name, store in (('stored', True), ('fused', False)):
+        sims[name] = rt.Simulation2D(env, source)
+        sims[name].cast(angles, store=store, **kw)
+    H = {'stored': sims['stored'].heatmap_full(resolution=res, freq=freq, stream=False)[0].cpu().numpy(),
+         'stream': sims['stored'].heatmap_full(resolution=res, freq=freq, stream=True)[0].cpu().numpy(),
+         'fused': sims['fused'].heatmap_full(resolution=res, freq=freq)[0].cpu().numpy()}
+    ref = H['stored']
+    for name in ('stream', 'fused'):
+        assert H[name].shape == ref.shape
+        assert np.array_equal(np.isfinite(H[name]), np.isfinite(ref)) and np.array_equal(H[name] == 0, ref == 0), name
+        m = np.isfinite(ref) & (ref != 0)
+        assert (np.abs(H[name] - ref)[m] / np.abs(ref[m])).max(initial=0) < 1e-12, name
+    print(f'seed {seed}: res {res}, freq {freq}, map {ref.shape}, {int((ref != 0).sum())} cells hit')
