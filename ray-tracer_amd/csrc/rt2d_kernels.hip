@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     for (int i = 0; i < p.n_steps_max; ++i) {
         // step sizing (ray.py:153-154)
         const bool steep = fabs(dx_z) > dx_z_max;
-        if (POST >= 1) slope_max = fmax(slope_max, fabs(dx_z));
+        if (POST >= 1) slope_max = vmax(slope_max, fabs(dx_z));
         {
             double s = p.dx_max;
             if (__any(steep)) {                  // wave-uniform: a wave of shallow rays never pays for the division
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         bool final_pt = false;                 // the point about to be accepted is the ray's last (max-rebounds)
         // (branch hints: a wave alone on its CU pays an instruction-fetch stall at every taken branch, so the common
         // step should be laid out as straight-line code)
-        if (__builtin_expect(general, 0)) {
+        if (__builtin_expect(__any(general), 0)) if (general) {
             if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
             // clipped in x is still inside in z; the clipped point is NOT appended
@@ -680,8 +680,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         const double dz_c = rt2d_quad_of(rz, dzr, 1);
         if (FULL || (WRITE && pc)) c_pt = c;
         if (POST >= 1) {
-            min_x = fmin(min_x, x); max_x = fmax(max_x, x);
-            min_z = fmin(min_z, z); max_z = fmax(max_z, z);
+            min_x = vmin(min_x, x); max_x = vmax(max_x, x);        // bare instructions: see vmax / vmin above
+            min_z = vmin(min_z, z); max_z = vmax(max_z, z);
         }
         if (FULL && has_target) tt.add(x, z, T, n_pts, tx);
         if (WRITE && __builtin_expect(n_pts < room, 1)) {
