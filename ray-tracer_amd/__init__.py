@@ -12,6 +12,7 @@ from .environment import Environment2D  # noqa: F401
 from .rays import RayFan, Ray2D, RayPack2D  # noqa: F401
 from .simulation import Simulation2D, EigenraySim2D  # noqa: F401
 from .bathymetry import Map  # noqa: F401
+from .presentation import heatmap_ticks, floor_mask, heatmap_image, plot_heatmap  # noqa: F401
 from . import _lib  # noqa: F401
 
 build = _lib.build

@@ -145,6 +145,13 @@ class Simulation2D:
             pack.populate(*freqs)
         return {f: self.heatmap(freq=f, **kwargs) for f in freqs}
 
+    def plot_heatmap(self, ax=None, floor=True, **kwargs):
+        """heatmap(**kwargs) drawn with metre ticks and the sea floor painted over it (deprecated.ipynb cell 4)."""
+        from . import presentation
+        res = kwargs.get('resolution', np.array([50, 25]))
+        show = {k: kwargs.pop(k) for k in ('cmap', 'vmin', 'vmax', 'aspect') if k in kwargs}
+        return presentation.plot_heatmap(self.heatmap(**kwargs), res, env=self.env if floor else None, ax=ax, **show)
+
     def plot(self, fig, **kwargs):
         pack = kwargs.pop('pack', self.pack_default)
         for ray in self.raypacks[pack].rays:
