@@ -57,35 +57,28 @@ __device__ __forceinline__ int64_t rt2d_floordiv(int64_t a, int64_t b) {
 
 // Cell indices of a point: ix = int(x) // res_x, iz = int(z) // (-res_z) (simulation.py:123-125: C truncation, then
 // Python floor division).  64-bit integer division costs ~150 instructions on this hardware and there are two per
-// point, so coordinates below 2^31 take a reciprocal multiply with an exact remainder fix-up instead: t and b are
-// integers, fma(-q, b, t) is exact, and q = floor(t * (1/b)) can only be one off when t/b is an integer.
+// point, so coordinates below 2^31 take a reciprocal multiply instead: for integers |t| < 2^31 and 1 <= b < 2^20,
+// floor((t + 0.5) * RN(1/b)) == t // b exactly -- (t + 0.5) / b is at least 0.5 / b away from every integer, and the
+// two roundings move the product by less than 2^-21 / b (tests/test_host.py::test_half_offset_floor_division).
 struct HeatGeom { int32_t res_x, res_z; double rx, rz, inv_rx, inv_rz, lim; };     // lim: |coordinate| bound of the fast division
 
-__device__ __forceinline__ int64_t rt2d_fdiv_pos(double t, double b, double inv_b) {     // floor(t / b), b > 0
-    double q = floor(t * inv_b);
-    double rem = fma(-q, b, t);
-    if (rem < 0.0) q -= 1.0; else if (rem >= b) q += 1.0;
-    return (int64_t)(int32_t)q;
-}
+__device__ __forceinline__ double rt2d_fdiv_pos(double t, double inv_b) { return floor((t + 0.5) * inv_b); }     // t // b
 
 __device__ __forceinline__ void rt2d_cell_xz(const HeatGeom& g, double x, double z, int64_t& ix, int64_t& iz) {
     if (fabs(x) < g.lim && fabs(z) < g.lim) {
-        ix = rt2d_fdiv_pos(trunc(x), g.rx, g.inv_rx);
-        iz = rt2d_fdiv_pos(-trunc(z), g.rz, g.inv_rz);          // a // (-b) == (-a) // b
+        ix = (int64_t)(int32_t)rt2d_fdiv_pos(trunc(x), g.inv_rx);
+        iz = (int64_t)(int32_t)rt2d_fdiv_pos(-trunc(z), g.inv_rz);          // a // (-b) == (-a) // b
     } else {
         ix = rt2d_floordiv((int64_t)x, g.res_x);
         iz = rt2d_floordiv((int64_t)z, -1 * (int64_t)g.res_z);
     }
 }
 
-// The same cell in 32-bit arithmetic, for callers that treat coordinates beyond 2^31 as an error (returns false there)
+// The same cell in 32-bit arithmetic, for callers that treat coordinates beyond 2^31 as an error (returns false there;
+// their geometry has res < 2^20)
 __device__ __forceinline__ bool rt2d_cell_i32(const HeatGeom& g, double x, double z, int& ix, int& iz) {
-    const double tx = trunc(x), tz = -trunc(z);
-    double qx = floor(tx * g.inv_rx), qz = floor(tz * g.inv_rz);
-    const double remx = fma(-qx, g.rx, tx), remz = fma(-qz, g.rz, tz);
-    if (remx < 0.0) qx -= 1.0; else if (remx >= g.rx) qx += 1.0;
-    if (remz < 0.0) qz -= 1.0; else if (remz >= g.rz) qz += 1.0;
-    ix = (int)qx; iz = (int)qz;
+    ix = (int)rt2d_fdiv_pos(trunc(x), g.inv_rx);
+    iz = (int)rt2d_fdiv_pos(-trunc(z), g.inv_rz);
     return fabs(x) < 2147483648.0 && fabs(z) < 2147483648.0;
 }
 
@@ -125,10 +118,15 @@ __device__ __forceinline__ double rt2d_exp2(double t) {
     return ldexp(p, (int)n);
 }
 
-__device__ __forceinline__ double rt2d_heat_val(double g) {
-    if (g > -3000.0 && g < 3000.0) return rt2d_exp2(g * -0.033219280948873623);     // -log2(10)/100
+__device__ __forceinline__ bool rt2d_heat_val_is_plain(double g) { return g > -3000.0 && g < 3000.0; }
+__device__ __forceinline__ double rt2d_heat_val_plain(double g) { return rt2d_exp2(g * -0.033219280948873623); }   // -log2(10)/100
+__device__ __forceinline__ double rt2d_heat_val_pows(double g) {
     double tmult = pow(10.0, g / 10);
     return pow(tmult, -0.1);
+}
+__device__ __forceinline__ double rt2d_heat_val(double g) {
+    if (rt2d_heat_val_is_plain(g)) return rt2d_heat_val_plain(g);
+    return rt2d_heat_val_pows(g);
 }
 
 
@@ -140,9 +138,11 @@ __device__ __forceinline__ double rt2d_heat_val(double g) {
 // row_bcast:31 = 0x143 across rows); lanes without a source read 0
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double rt2d_dpp(double v) {
+    // mov_dpp with bound_ctrl: lanes without a source read 0 and there is no previous value to preserve (a row that
+    // ROW_MASK leaves out gets an unspecified value: the callers below never use it there)
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, true);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
@@ -155,17 +155,19 @@ __device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, dou
     const unsigned long long heads = __ballot(head);
     const int head_pos = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));    // head of this lane's run
     // Segmented inclusive scan, all in the vector ALU: four shifts inside each row of 16 lanes, then the two row
-    // broadcasts that carry a run across rows.  A lane only adds a value that comes from its own run.
+    // broadcasts that carry a run across rows.  A lane only adds a value that comes from its own run: `reach` is how
+    // far below itself a lane may look inside its row, -1 for lanes that do not deposit.
     double v = want ? val : 0.0;
-    const int in_row = lane & 15;
-    { const double u = rt2d_dpp<0x111, 0xf>(v); if (want && in_row >= 1 && lane - 1 >= head_pos) v += u; }
-    { const double u = rt2d_dpp<0x112, 0xf>(v); if (want && in_row >= 2 && lane - 2 >= head_pos) v += u; }
-    { const double u = rt2d_dpp<0x114, 0xf>(v); if (want && in_row >= 4 && lane - 4 >= head_pos) v += u; }
-    { const double u = rt2d_dpp<0x118, 0xf>(v); if (want && in_row >= 8 && lane - 8 >= head_pos) v += u; }
+    const int dist = lane - head_pos;
+    const int reach = want ? min(lane & 15, dist) : -1;
+    { const double u = rt2d_dpp<0x111, 0xf>(v); v += (reach >= 1) ? u : 0.0; }
+    { const double u = rt2d_dpp<0x112, 0xf>(v); v += (reach >= 2) ? u : 0.0; }
+    { const double u = rt2d_dpp<0x114, 0xf>(v); v += (reach >= 4) ? u : 0.0; }
+    { const double u = rt2d_dpp<0x118, 0xf>(v); v += (reach >= 8) ? u : 0.0; }
     { const double u = rt2d_dpp<0x142, 0xa>(v);                                  // rows 1 and 3 <- lane 15 / 47
-      const int from = (lane & ~15) - 1; if (want && (lane & 16) && from >= head_pos) v += u; }
+      v += (want && (lane & 16) && dist > (lane & 15)) ? u : 0.0; }
     { const double u = rt2d_dpp<0x143, 0xc>(v);                                  // rows 2 and 3 <- lane 31
-      if (want && lane >= 32 && 31 >= head_pos) v += u; }
+      v += (want && lane >= 32 && head_pos <= 31) ? u : 0.0; }
     const bool tail = want && (lane == RT2D_WAVE - 1 || !((act >> (lane + 1)) & 1ull) || ((heads >> (lane + 1)) & 1ull));
     if (tail) atomicAdd(&H[cell], v);
 }
@@ -271,6 +273,14 @@ __device__ __forceinline__ double rt2d_div_by_const(double a, double b, double y
     double q1 = fma(r0, y, q0);
     double r1 = fma(-q1, b, a);
     return fma(r1, y, q1);
+}
+
+// a / 1000 of the gain integrand (ray.py:346): five FMAs instead of the 13-instruction division (with its quarter-rate
+// reciprocal) in every (point, frequency) of the gain loops; outside the range the identity is tested on, divide.
+__device__ __forceinline__ double rt2d_div_1000(double a) {
+    const double m = fabs(a);
+    if (__builtin_expect(m > 0x1p-200 && m < 0x1p200, 1)) return rt2d_div_by_const(a, 1000.0, 0.001);
+    return a / 1000;
 }
 
 __device__ __forceinline__ double rt2d_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
@@ -666,7 +676,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 double rec[20];
                 if (FUSE) rt2d_lookup<19>((const double*)s_abs, ab_lds, z, rec);
                 else rt2d_lookup<19>(gtab, e.absorb, z, rec);              // factors at the START of the segment, ray.py:346
-                double dG = -1 * rt2d_alpha(rec, z - rec[0], g_ff) / 1000 * dL;
+                double dG = rt2d_div_1000(-1 * rt2d_alpha(rec, z - rec[0], g_ff)) * dL;
                 g_S += dG;
                 g_pt = g_S + g_A;
                 cut = CUTOFF && !final_pt && g_pt < a.g_cut;
@@ -954,7 +964,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
             double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
             double alpha_3 = k_A3 * ff[k];
             double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
-            double dG = -1 * alpha / 1000 * dL;                            // ray.py:346
+            double dG = rt2d_div_1000(-1 * alpha) * dL;                            // ray.py:346
             S[k] += dG;                                                    // ray.py:347
             if (a.G && k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = S[k] + A[k];
         }
@@ -1014,7 +1024,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_dg_kernel(const GainArgs a) {
             double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
             double alpha_3 = k_A3 * ff[k];
             double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
-            double dG = -1 * alpha / 1000 * dL;                            // ray.py:346
+            double dG = rt2d_div_1000(-1 * alpha) * dL;                            // ray.py:346
             if (k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = dG;
         }
     }
@@ -1183,7 +1193,7 @@ __global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatAr
             ++next_reb;
             next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
         }
-        double dG = -1 * rt2d_alpha(rec, zp - rec[0], ff) / 1000 * dL;      // ray.py:346
+        double dG = rt2d_div_1000(-1 * rt2d_alpha(rec, zp - rec[0], ff)) * dL;      // ray.py:346
         S += dG;                                                           // ray.py:347
         const double g = S + A;
         if (binme) binner.point(b.bin, x, z, g, lane);
@@ -1251,36 +1261,52 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     const bool hinted = (flags & 2) != 0;               // caller vouches for monotone columns and in-map points
     int np = mine ? a.n_pts[r] : 0;
     const int64_t base = a.tile_off[tile] + lane;
+    const int nx = (int)a.nx, nz = (int)a.nz;
     int tmax = np;
     for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
 
-    // forward check, HM_UNROLL rows in flight per lane
+    // Loads are unconditional, from a row index clamped into the ray (row 0 of the tile exists for every lane): with
+    // a load per live lane behind a branch the compiler sinks the first use into the branch and waits there, which
+    // turns HM_UNROLL loads in flight into HM_UNROLL round trips.
+    int last = max(np, 1) - 1;
+
+    // forward check, HM_UNROLL rows in flight per lane.  The launcher only uses this kernel when every in-map point
+    // has |x|, |z| < 2^31 (shape * resolution below that), so the 32-bit cell arithmetic decides "inside the map" exactly.
     bool ok = true;
-    int64_t prev_ix = INT64_MIN;
+    int prev_ix = INT32_MIN;
     const int t_check = __all(hinted || !mine) ? 0 : tmax;
     for (int s0 = 0; s0 < t_check; s0 += HM_UNROLL) {
         double xs[HM_UNROLL], zs[HM_UNROLL];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
-            const int s = s0 + u;
-            const int64_t o = base + (int64_t)s * RT2D_WAVE;
-            xs[u] = (s < np) ? a.X[o] : 0.0;
-            zs[u] = (s < np) ? a.Z[o] : 0.0;
+            const int64_t o = base + (int64_t)min(s0 + u, last) * RT2D_WAVE;
+            xs[u] = a.X[o];
+            zs[u] = a.Z[o];
         }
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
             if (s0 + u < np) {
-                int64_t ix, iz;
-                rt2d_cell_xz(a.geo, xs[u], zs[u], ix, iz);
-                ok = ok && ix >= prev_ix && ix >= 0 && ix < a.nx && iz >= 0 && iz < a.nz;
+                int ix, iz;
+                const bool in_range = rt2d_cell_i32(a.geo, xs[u], zs[u], ix, iz);
+                ok = ok && in_range && ix >= prev_ix && (unsigned)ix < (unsigned)nx && (unsigned)iz < (unsigned)nz;
                 prev_ix = ix;
             }
         }
     }
-    if (!ok && !hinted) {
-        int k = atomicAdd(&a.work[0], 1);
-        a.work[2 + k] = (int32_t)r;
-        np = 0;
+    // rays for the general kernel: one counter update per wave, and the rays of a tile stay together in the list (that
+    // kernel's lines are shared by neighbouring rays, see its item mapping)
+    const bool queued = !ok && !hinted;
+    const unsigned long long qmask = __ballot(queued);
+    if (qmask) {
+        const int leader = __ffsll((long long)qmask) - 1;
+        int k0 = 0;
+        if (lane == leader) k0 = atomicAdd(&a.work[0], __popcll(qmask));
+        k0 = __shfl(k0, leader);
+        if (queued) {
+            a.work[2 + k0 + __popcll(qmask & ((1ull << lane) - 1ull))] = (int32_t)r;
+            np = 0;
+            last = 0;
+        }
     }
     tmax = np;
     for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
@@ -1289,74 +1315,84 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     unsigned long long seen[MW];
 #pragma unroll
     for (int w = 0; w < MW; ++w) seen[w] = 0ull;
-    int64_t cur_ix = -1;
+    int cur_ix = -1;
     for (int s0 = tmax - 1; s0 >= 0; s0 -= HM_UNROLL) {
         double xs[HM_UNROLL], zs[HM_UNROLL], gs[HM_UNROLL];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
-            const int s = s0 - u;
-            const int64_t o = base + (int64_t)s * RT2D_WAVE;
-            const bool live = s >= 0 && s < np;
-            xs[u] = live ? a.X[o] : 0.0;
-            zs[u] = live ? a.Z[o] : 0.0;
-            gs[u] = live ? a.G[o] : 0.0;
+            const int64_t o = base + (int64_t)min(max(s0 - u, 0), last) * RT2D_WAVE;
+            xs[u] = a.X[o];
+            zs[u] = a.Z[o];
+            gs[u] = a.G[o];
         }
+        unsigned late = 0u;                                 // rows of this batch whose value needs the two pows
+        int late_cell[HM_UNROLL];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
             const int s = s0 - u;
             bool fresh = false;
-            int64_t cell = -1 - lane;                       // unique per lane: never merges
+            int cell = -1 - lane;                           // unique per lane: never merges
             double val = 0.0;
+            late_cell[u] = 0;
             if (s >= 0 && s < np) {
-                int64_t ix, iz;
-                rt2d_cell_xz(a.geo, xs[u], zs[u], ix, iz);
+                int ix, iz;
+                rt2d_cell_i32(a.geo, xs[u], zs[u], ix, iz);
                 if (ix != cur_ix) {
                     cur_ix = ix;
 #pragma unroll
                     for (int w = 0; w < MW; ++w) seen[w] = 0ull;
                 }
                 const unsigned long long bit = 1ull << (iz & 63);
-                const int word = (int)(iz >> 6);
+                const int word = iz >> 6;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) if (w == word) { fresh = (seen[w] & bit) == 0; seen[w] |= bit; }
                 if (fresh) {
-                    val = rt2d_heat_val(gs[u]);                                // ray.py:317, simulation.py:129
-                    cell = ix * a.nz + iz;
+                    cell = ix * nz + iz;
+                    if (__builtin_expect(rt2d_heat_val_is_plain(gs[u]), 1)) val = rt2d_heat_val_plain(gs[u]);   // ray.py:317, simulation.py:129
+                    else { fresh = false; late |= 1u << u; late_cell[u] = cell; }
                 }
             }
-            // Neighbouring lanes are neighbouring angles: at one step they mostly sit in the same cell.  Sum runs of
-            // equal cells across the wave (segmented scan) and let the last lane of each run issue ONE atomic.
-            if (__any(fresh)) {
-                const int c32 = (int)cell;
-                const int c_prev = __shfl_up(c32, 1);
-                const bool head = (lane == 0) || (c_prev != c32);
-                const unsigned long long heads = __ballot(head);
-                const int run = __popcll(heads & (~0ull >> (63 - lane)));   // run index: equal <=> same run of equal cells
+            // Neighbouring lanes are neighbouring angles: at one step they mostly sit in the same cell.  Runs of
+            // equal cells across the wave are summed and the last lane of each run issues ONE atomic.
+            rt2d_deposit(a.H, fresh, cell, val, lane);
+        }
+        // gains beyond +-3000 dB (a surface coefficient that underflowed to 0 at high frequency): the pow pair of the
+        // reference, kept out of the loop above and present once in the program
+        while (__builtin_expect(late != 0u, 0)) {
+            const int u = __ffs(late) - 1;
+            late &= late - 1u;
+            double g = gs[0]; int cell = late_cell[0];
 #pragma unroll
-                for (int off = 1; off < RT2D_WAVE; off <<= 1) {
-                    double v_up = __shfl_up(val, off);
-                    int run_up = __shfl_up(run, off);
-                    if (lane >= off && run_up == run) val += v_up;
-                }
-                const bool tail = (lane == RT2D_WAVE - 1) || ((heads >> (lane + 1)) & 1ull);
-                if (fresh && tail) atomicAdd(&a.H[cell], val);
-            }
+            for (int k = 1; k < HM_UNROLL; ++k) if (u == k) { g = gs[k]; cell = late_cell[k]; }
+            atomicAdd(&a.H[cell], rt2d_heat_val_pows(g));
         }
     }
 }
 
-// General path: one wave per ray, any trajectory.  The cell of every point is computed once into LDS (rays longer than
-// the cell cache recompute it from global memory); "last write wins" is resolved by an LDS hash cell -> last step, in
-// partitions when the ray has more candidate cells than half the hash.
-__global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
+// General path: one workgroup of HM_THREADS per ray, any trajectory.  The cell of every point is computed once into LDS
+// (rays longer than the cell cache recompute it from global memory); "last write wins" is resolved by an LDS hash
+// cell -> last step, in partitions when the ray has more candidate cells than half the hash.  The LDS of a ray (48 KB
+// at the default sizes) allows three rays per CU whatever the workgroup size, and a ray is a chain of dependent phases:
+// four waves per ray shorten every phase of an ~800-point ray to one or two points per lane.
+#ifndef HM_THREADS
+#define HM_THREADS 256
+#endif
+__global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
+    __shared__ int s_red[2];
     int32_t* s_cell = reinterpret_cast<int32_t*>(s_hash + a.cap);
     const int lane = threadIdx.x;
     const int64_t size = a.nx * a.nz;
     const uint32_t mask = (uint32_t)a.cap - 1;
     // rays come either from the queue the fast kernel filled (work != NULL) or straight from the mask
     const int64_t n_items = a.work ? (int64_t)a.work[0] : a.n;
-    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // One lane reads one point of the ray, i.e. a wave touches 64 different 128-byte lines of the tile layout, each of
+    // which also holds the same point of the ray's 15 neighbours.  Workgroups go to the 8 XCDs round-robin, so items
+    // are dealt in groups of 16 consecutive list entries per XCD: the neighbours' workgroups then run on the same L2 at
+    // about the same time and a line is fetched once for the group instead of once per ray (grid: a multiple of 128).
+    const int64_t b_xcd = blockIdx.x & 7, b_in = blockIdx.x >> 3;
+    const int64_t first_item = ((b_in >> 4) * 8 + b_xcd) * 16 + (b_in & 15);
+    for (int64_t item = first_item; item < n_items; item += gridDim.x) {
         const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
         if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
         const int np = a.n_pts[r];
@@ -1370,17 +1406,17 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
 
         // pass 0: cells (four independent loads per lane in flight), dropped points
         int n_drop = 0;
-        for (int s0 = 0; s0 < np; s0 += 4 * RT2D_WAVE) {
+        for (int s0 = 0; s0 < np; s0 += 4 * HM_THREADS) {
             double xs[4], zs[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int sc = min(s0 + u * RT2D_WAVE + lane, np - 1);
+                const int sc = min(s0 + u * HM_THREADS + lane, np - 1);
                 const int64_t o = base + (int64_t)sc * RT2D_WAVE;
                 xs[u] = a.X[o]; zs[u] = a.Z[o];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int sx = s0 + u * RT2D_WAVE + lane;
+                const int sx = s0 + u * HM_THREADS + lane;
                 if (sx < np) {
                     const int32_t cell = (int32_t)rt2d_cell(a.geo, xs[u], zs[u], a.nz, size);
                     if (cached) s_cell[sx] = cell;
@@ -1388,22 +1424,26 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
                 }
             }
         }
+        if (lane < 2) s_red[lane] = 0;
         __syncthreads();
         int n_cand = 0;
-        for (int sx = lane; sx < np; sx += RT2D_WAVE) {
+        for (int sx = lane; sx < np; sx += HM_THREADS) {
             const int32_t cell = cell_at(sx);
             const int32_t nxt = (sx + 1 < np) ? cell_at(sx + 1) : -2;
             n_cand += (cell >= 0) & (nxt != cell);
         }
         for (int off = 32; off > 0; off >>= 1) { n_cand += __shfl_xor(n_cand, off); n_drop += __shfl_xor(n_drop, off); }
+        if ((lane & 63) == 0) { atomicAdd(&s_red[0], n_cand); atomicAdd(&s_red[1], n_drop); }
+        __syncthreads();
+        n_cand = s_red[0]; n_drop = s_red[1];
         if (lane == 0 && n_drop && a.n_dropped) atomicAdd((unsigned long long*)a.n_dropped, (unsigned long long)n_drop);
         const int parts = max(1, (2 * n_cand + a.cap - 1) / a.cap);        // load factor <= 1/2 per partition
 
         for (int part = 0; part < parts; ++part) {
-            for (int i = lane; i < a.cap; i += RT2D_WAVE) s_hash[i] = HM_EMPTY;
+            for (int i = lane; i < a.cap; i += HM_THREADS) s_hash[i] = HM_EMPTY;
             __syncthreads();
             // pass A: cell -> max step
-            for (int sx = lane; sx < np; sx += RT2D_WAVE) {
+            for (int sx = lane; sx < np; sx += HM_THREADS) {
                 const int32_t cell = cell_at(sx);
                 if (cell < 0) continue;
                 if (sx + 1 < np && cell_at(sx + 1) == cell) continue;
@@ -1419,13 +1459,13 @@ __global__ void __launch_bounds__(64) rt2d_heatmap_kernel(const HeatArgs a) {
                 }
             }
             __syncthreads();
-            // pass B: the step that owns its cell deposits (simulation.py:129-131); eight points per lane at a time so
+            // pass B: the step that owns its cell deposits (simulation.py:129-131); up to eight points per lane at a time so
             // that their gain loads travel together
-            for (int s0 = 0; s0 < np; s0 += 8 * RT2D_WAVE) {
+            for (int s0 = 0; s0 < np; s0 += 8 * HM_THREADS) {
                 int32_t own[8]; double gv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int sx = s0 + u * RT2D_WAVE + lane;
+                    const int sx = s0 + u * HM_THREADS + lane;
                     own[u] = -1;
                     gv[u] = 0.0;
                     if (sx >= np) continue;
@@ -1961,7 +2001,10 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
     // below ~16k rays the latter finishes first
     static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 16384;
-    const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays;
+    // (the tile kernel works on 32-bit cells: every point inside the map must have |x|, |z| < 2^31)
+    const bool small_coords = res[0] < (1 << 20) && res[1] < (1 << 20) &&
+                              (int64_t)shape[0] * res[0] < (1ll << 31) && (int64_t)shape[1] * res[1] < (1ll << 31);
+    const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays && small_coords;
     if (work && !fast) HIP_OK(hipMemsetAsync(work, 0xff, sizeof(int32_t), stream));     // work[0] = -1: every ray went general
     if (fast) {
         a.work = work;
@@ -1974,8 +2017,8 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
         HIP_OK(hipGetLastError());
     }
     // general kernel: everything (no workspace) or what the fast kernel queued; blocks stride over the items
-    const int64_t blocks = n < 16384 ? n : 16384;
-    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(RT2D_WAVE), (size_t)a.cap * 8 + (size_t)a.cell_cap * 4, stream, a);
+    const int64_t blocks = n < 16384 ? (n + 127) / 128 * 128 : 16384;
+    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(HM_THREADS), (size_t)a.cap * 8 + (size_t)a.cell_cap * 4, stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

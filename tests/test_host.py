@@ -135,3 +135,45 @@ def test_raypack_bookkeeping_without_gpu(rt):
     assert list(pack.dist_sorted) == [1.0, 3.0]
     assert pack.dist[1.0][0] is rays[1] and pack.angles[-0.1] is rays[0]
     assert len(pack.stop_reasons['exit-xmax']) == 2
+
+
+def test_argument_checks_answer_before_any_gpu_work(rt):
+    """Every entry point rejects null / negative arguments with a negative status and a message (include/rt2d.h:
+    "every call returns int32 status, message via rt2d_last_error"); these checks run before the first HIP call, so
+    they hold on a machine without a GPU."""
+    import ctypes as C
+    L = rt._lib.lib()
+    calls = {
+        'rt2d_env_create': (None, None),
+        'rt2d_env_surface_speed': (None, None),
+        'rt2d_traj_layout': (None, 4, None, None, None),
+        'rt2d_dist': (None, None, None, None, 4, None, None, None),
+        'rt2d_heatmap_finalize': (None, None, 0.02, 0.5, None, None, None),
+    }
+    for name, args in calls.items():
+        rc = getattr(L, name)(*args)
+        assert rc < 0, name
+        msg = L.rt2d_last_error().decode()
+        assert name.replace('rt2d_', '') in msg or 'null' in msg, (name, msg)
+    # an environment whose tables are malformed never reaches the device either
+    g = common.load('c1_flat250')
+    env = common.product_env(rt, g)
+    desc, keep = env.env_desc()
+    desc.floor.n_pieces = 0
+    handle = C.c_void_p()
+    assert L.rt2d_env_create(C.byref(desc), C.byref(handle)) < 0
+    assert b'floor' in L.rt2d_last_error() and not handle.value
+
+
+def test_half_offset_floor_division():
+    """The identity the heat-map kernels use for int(x) // res (csrc/rt2d_kernels.hip, rt2d_fdiv_pos): for integers
+    |t| < 2^31 and 1 <= b < 2^20, floor((t + 0.5) * RN(1/b)) == t // b, in double arithmetic as the device does it."""
+    rng = np.random.default_rng(0)
+    for b in [1, 2, 3, 5, 7, 10, 25, 49, 50, 51, 100, 999, 1000, 4096, 65535, (1 << 20) - 1]:
+        inv = np.float64(1.0) / np.float64(b)
+        ks = rng.integers(-(2 ** 31) // b, (2 ** 31) // b, 50000)
+        t = np.concatenate([ks * b, ks * b + 1, ks * b - 1, ks * b + b // 2, rng.integers(-2 ** 31 + 1, 2 ** 31 - 1, 100000),
+                            np.array([0, 1, -1, 2 ** 31 - 1, -2 ** 31 + 1])])
+        t = t[(t > -2 ** 31) & (t < 2 ** 31)]
+        q = np.floor((t.astype(np.float64) + 0.5) * inv).astype(np.int64)
+        assert np.array_equal(q, t // b), b

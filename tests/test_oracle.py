@@ -171,8 +171,8 @@ def test_edge_cases(orc):
     assert np.isnan(r.dist_to_target)
 
 
-@pytest.mark.parametrize('b', [50., 10., 0.1, 25., 7.3, 3., 1e-3, 12345.678])
+@pytest.mark.parametrize('b', [50., 10., 0.1, 25., 7.3, 3., 1e-3, 12345.678, 1000.])
 def test_div_by_const(orc, b):
     """The identity behind rt2d_div_by_const (csrc/rt2d_kernels.hip): with y = RN(1/b), two FMA correction steps on a*y
-    give the IEEE quotient a/b bit for bit.  The stepping kernel uses it for k1/k0 when k0 = +-dx_max (ray.py:243)."""
+    give the IEEE quotient a/b bit for bit.  The stepping kernel uses it for k1/k0 when k0 = +-dx_max (ray.py:243), the gain loops for alpha / 1000 (ray.py:346)."""
     assert orc.lib().orc_check_div_by_const(b, 1_000_000, 12345) == 0
