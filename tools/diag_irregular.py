@@ -33,3 +33,22 @@ for i in bad[:: max(1, len(bad) // 400)]:
 print('sample of non-monotone rays: (backward steps, where, stop) -> count')
 for k, v in sorted(hist.items(), key=lambda kv: -kv[1])[:12]:
     print(' ', k, v)
+
+# how far behind its own column frontier does a ray step, and how many columns does one step jump?
+res_x = 50
+cnt = {'col-monotone': 0, 'P&P1': 0, 'other': 0}
+worst_back = 0
+for i in bad[:: max(1, len(bad) // 2000)]:
+    xz = rt.Ray2D._from_fan(fan, int(i)).XZ
+    col = np.trunc(xz[:, 0]).astype(np.int64) // res_x
+    front = np.maximum.accumulate(col)
+    behind = int((front - col).max())
+    jump = int(np.abs(np.diff(col)).max())
+    worst_back = max(worst_back, behind)
+    if behind == 0:
+        cnt['col-monotone'] += 1
+    elif behind <= 1 and jump <= 1:
+        cnt['P&P1'] += 1
+    else:
+        cnt['other'] += 1
+print('column pattern of sampled non-monotone rays:', cnt, 'worst columns behind the frontier', worst_back)
