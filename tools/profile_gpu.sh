@@ -5,6 +5,8 @@
 #   trace/   rocprofv3 --kernel-trace --stats   (per-dispatch durations: 999-ray fan and the 1M-ray large fan)
 #   fetch/   rocprofv3 --pmc FETCH_SIZE         (HBM read traffic per dispatch; its own pass, no tracing domains)
 #   write/   rocprofv3 --pmc WRITE_SIZE         (HBM write traffic per dispatch; its own pass)
+#   valu/    rocprofv3 --pmc 8 SQ counters      (vector / scalar instructions issued, FP64 op mix, waves; its own pass)
+#   atomic/  rocprofv3 --pmc TCC_ATOMIC_sum ... (L2 atomic requests per dispatch; its own pass)
 # tools/summarize_profile.py turns them into the files committed under profiles/.
 # Every step has its own time limit and the chain stops at the first failure.
 set -e
@@ -21,4 +23,8 @@ timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetc
 echo "fetch done"
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 $BENCH --steps 3 --warmup 1 --large-steps 2 > "$OUT/write.log" 2>&1
 echo "write done"
+timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --output-format csv -d "$OUT/valu" -o v -- python3 $BENCH --steps 3 --warmup 1 --large-steps 2 > "$OUT/valu.log" 2>&1
+echo "valu done"
+timeout -s KILL 240 rocprofv3 --pmc TCC_ATOMIC_sum TCC_REQ_sum --output-format csv -d "$OUT/atomic" -o a -- python3 $BENCH --steps 3 --warmup 1 --large-steps 2 > "$OUT/atomic.log" 2>&1
+echo "atomic done"
 ls -R "$OUT" | head -40

@@ -10,6 +10,12 @@ Writes profiles/ROUND_DIR/TAG_kernel_stats.csv   rocprofv3's own --stats summary
                                                  FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled
                                                  (calibrated there on wide coalesced streaming reads); WRITE_SIZE is exact
                                                  for streaming stores and atomics.
+       profiles/ROUND_DIR/TAG_counters.json      (when the valu / atomic passes ran) per launch: vector and scalar
+                                                 instructions issued, the FP64 op mix, waves, LDS instructions, L2
+                                                 atomic requests; with the launch duration of the trace pass: FP64 flop/s
+                                                 as a fraction of the 78.6 TFLOP/s vector peak (a wave instruction
+                                                 counts 64 lanes, FMA twice: an upper bound where lanes are masked off)
+                                                 and atomics per second.
 bench.py reads TAG_traffic.json of the newest committed profile for `roofline.traffic`.
 """
 
@@ -79,6 +85,39 @@ def main():
     with open(os.path.join(dst, f'{tag}_traffic.json'), 'w') as f:
         json.dump(dict(units='bytes per launch; FETCH_SIZE [KiB] x 1024 x 2 (gfx950), WRITE_SIZE [KiB] x 1024',
                        kernels=traffic), f, indent=1)
+    # optional passes: instruction mix and L2 atomics
+    names = ('SQ_INSTS_VALU', 'SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64',
+             'SQ_INSTS_VALU_TRANS_F64', 'SQ_INSTS_SALU', 'SQ_WAVES', 'SQ_INSTS_LDS', 'TCC_ATOMIC_sum', 'TCC_REQ_sum')
+    cnt = defaultdict(lambda: defaultdict(list))
+    for sub, fname in (('valu', 'v_counter_collection.csv'), ('atomic', 'a_counter_collection.csv')):
+        path = os.path.join(src, sub, fname)
+        if os.path.exists(path):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if 'rt2d_' in row['Kernel_Name'] and row['Counter_Name'] in names:
+                        key = (short(row['Kernel_Name']), int(row['Grid_Size']), int(row['Workgroup_Size']))
+                        cnt[key][row['Counter_Name']].append(float(row['Counter_Value']))
+    if cnt:
+        out = {}
+        for key in sorted(cnt, key=lambda k: (k[0], k[1])):
+            c = {nm: sum(v) / len(v) for nm, v in cnt[key].items()}
+            d = groups.get(key)
+            if d:
+                t = sum(d) / len(d) * 1e-9
+                c['avg_ns'] = sum(d) / len(d)
+                if 'SQ_INSTS_VALU_FMA_F64' in c:
+                    flop = 64 * (2 * c['SQ_INSTS_VALU_FMA_F64'] + c.get('SQ_INSTS_VALU_MUL_F64', 0) +
+                                 c.get('SQ_INSTS_VALU_ADD_F64', 0) + c.get('SQ_INSTS_VALU_TRANS_F64', 0))
+                    c['fp64_flop_upper_bound'] = flop
+                    c['fp64_vector_frac_of_78.6_TFLOPs'] = flop / t / 78.6e12
+                if 'SQ_INSTS_VALU' in c:
+                    c['valu_insts_per_s'] = c['SQ_INSTS_VALU'] / t
+                    c['valu_issue_frac'] = c['SQ_INSTS_VALU'] * 4 / (t * 2.4e9 * 1024)     # 4 cycles per wave64 op, 1024 SIMDs, 2.4 GHz
+                if 'TCC_ATOMIC_sum' in c:
+                    c['atomics_per_s'] = c['TCC_ATOMIC_sum'] / t
+            out[f'{key[0]}|grid={key[1]}|wg={key[2]}'] = c
+        with open(os.path.join(dst, f'{tag}_counters.json'), 'w') as f:
+            json.dump(dict(units='counter values per launch (mean over the launches of the pass)', kernels=out), f, indent=1)
     for line in open(os.path.join(src, 'trace.log')):
         if line.startswith('{'):
             with open(os.path.join(dst, f'{tag}_bench.json'), 'w') as f:
