@@ -9,8 +9,9 @@
 __global__ void __launch_bounds__(256) burn(double* out, long long* cyc, long long* rt, int iters, double a, double b) {
     double x0 = threadIdx.x * 1e-3, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
     const long long c0 = clock64(), r0 = wall_clock64();
-    for (int i = 0; i < iters; ++i) {
-        x0 = fma(x0, a, b); x1 = fma(x1, a, b); x2 = fma(x2, a, b); x3 = fma(x3, a, b);
+    for (int i = 0; i < iters; i += 16) {
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep) { x0 = fma(x0, a, b); x1 = fma(x1, a, b); x2 = fma(x2, a, b); x3 = fma(x3, a, b); }
     }
     const long long c1 = clock64(), r1 = wall_clock64();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
