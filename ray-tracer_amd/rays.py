@@ -793,7 +793,8 @@ class RayPack2D:
         self.range_max_plot = np.zeros(2)
         self.size_plot = np.zeros(2)
         self.dist_sorted = None
-        self._angle_set = set()
+        self._angle_set = set()          # angles of rays added one by one
+        self._angle_blocks = []          # sorted angle arrays of the fans added whole
         self._dist_keys = []
         self._maps = None
         self.n_failed = 0        # rays whose status was an error and that were therefore not added
@@ -807,39 +808,66 @@ class RayPack2D:
         self.range_max_plot = np.maximum(self.range_max_plot, rmax)
         self.size_plot = self.range_max_plot - self.range_min_plot
 
+    def _known_angles(self, a):
+        """Boolean mask: which of the angles `a` the pack already holds."""
+        a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+        known = np.zeros(len(a), dtype=bool)
+        if self._angle_set:
+            known |= np.isin(a, np.fromiter(self._angle_set, dtype=np.float64, count=len(self._angle_set)))
+        for block in self._angle_blocks:
+            pos = np.minimum(np.searchsorted(block, a), len(block) - 1)
+            known |= block[pos] == a
+        return known
+
     def add_fan(self, fan, indices=None):
         """Add rays of a fan (all, or the given indices), skipping errored rays and angles already present."""
-        ang = fan.angles
+        ang = np.asarray(fan.angles, dtype=np.float64)
         status = fan.host('status')
         idx_all = np.arange(fan.n) if indices is None else np.asarray(indices, dtype=np.int64)
-        keep = []
-        for i in idx_all:
-            a = float(ang[i])
-            if status[i] == RAY_ERR_INTERP:
-                self.n_failed += 1
-                continue
-            if a in self._angle_set:
-                continue
-            self._angle_set.add(a)
-            keep.append(int(i))
-        if not keep:
+        # whole-array form of the reference's per-ray loop (ray.py:451-465): errored rays are left out, an angle is kept
+        # the first time it is seen (a million-ray fan must not spend a second in a Python loop here)
+        ok = status[idx_all] != RAY_ERR_INTERP
+        self.n_failed += int((~ok).sum())
+        cand = idx_all[ok]
+        a = ang[cand]
+        step = np.diff(a)
+        rising, falling = bool((step > 0).all()), bool((step < 0).all())
+        if not (rising or falling):                            # a fan is normally a strictly monotonic sweep: all distinct
+            _, first = np.unique(a, return_index=True)         # index of the first occurrence of every distinct angle
+            if len(first) != len(a):
+                first.sort()
+                cand, a = cand[first], a[first]
+        if self._angle_set or self._angle_blocks:
+            fresh = ~self._known_angles(a)
+            if not fresh.all():
+                cand, a = cand[fresh], a[fresh]
+        if len(a):
+            self._angle_blocks.append(a.copy() if rising else a[::-1].copy() if falling else np.sort(a))
+        keep = cand
+        if not len(keep):
             return
         keep = np.asarray(keep, dtype=np.int64)
         self.rays._add_segment(fan, keep)
         self.n_rays += len(keep)
         self.n_angles += len(keep)
-        rng = fan.host('range')
-        self._fold_range(np.array([rng[0, keep].min(), rng[1, keep].min()]), np.array([rng[2, keep].max(), rng[3, keep].max()]))
+        if 'range' in fan._host or len(keep) < 4096:
+            rng = fan.host('range')
+            lo_hi = np.array([rng[0, keep].min(), rng[1, keep].min(), rng[2, keep].max(), rng[3, keep].max()])
+        else:                                                    # big fan: fold on the device, 4 numbers come back
+            torch = _torch()
+            rng = fan.range if len(keep) == fan.n else fan.range[:, torch.as_tensor(keep, device=fan.device)]
+            lo_hi = torch.cat((rng[:2].amin(dim=1), rng[2:].amax(dim=1))).cpu().numpy()
+        self._fold_range(lo_hi[:2], lo_hi[2:])
         if fan.target is not None:
             self._dist_keys.append(fan.host('dist')[keep])
         else:
-            self._dist_keys.append(np.full(len(keep), np.nan))   # placeholder for dist_to_target = None
+            self._dist_keys.append(np.array([np.nan]))           # placeholder for dist_to_target = None (one key, as in a dict)
         self._update_dist_sorted()
         self._maps = None
 
     def add(self, *rays):
         for ray in rays:
-            if ray.angle in self._angle_set:
+            if ray.angle in self._angle_set or self._known_angles(ray.angle)[0]:
                 continue
             self._angle_set.add(ray.angle)
             if ray._fan is not None:
