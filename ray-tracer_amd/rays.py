@@ -171,6 +171,7 @@ class RayFan:
             self.tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
             total = C.c_int64(0)
 
+            counted = False
             # Small fans: ONE speculative storing pass into a provisional layout with the same generous room for every
             # tile, then the exact layout and a compaction copy.  Valid when every ray fitted; otherwise (and for big
             # fans, where the padding would cost too much memory) count -> layout -> store.
@@ -201,6 +202,7 @@ class RayFan:
                     self._out = out
                     self.passes = 'speculative'
                     return
+                counted = not log_full                   # a ray outgrew the room: its points were still counted exactly
                 del X0, Z0, C0
             else:
                 room_p = min(int(self.kw['n_steps_max']) + 1, SPECULATIVE_ROOM)
@@ -224,14 +226,17 @@ class RayFan:
                         self.padded = True
                         self.passes = 'padded'
                         return
+                    counted = not log_full
                     del X0, Z0, C0
 
-            # pass 1: count points and rebounds only (no post-pass, no stores)
-            cnt = _lib.Rt2dRayOut()
-            cnt.n_pts, cnt.n_rebounds = self.n_pts.data_ptr(), self.n_rebounds.data_ptr()
-            p = self._params(0)
-            _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
-                                         _ptr(init_mult), C.byref(cnt), stream))
+            # pass 1: count points and rebounds only (no post-pass, no stores) -- unless a single-pass attempt above
+            # already did: it stops storing at its room but steps and counts to the end
+            if not counted:
+                cnt = _lib.Rt2dRayOut()
+                cnt.n_pts, cnt.n_rebounds = self.n_pts.data_ptr(), self.n_rebounds.data_ptr()
+                p = self._params(0)
+                _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
+                                             _ptr(init_mult), C.byref(cnt), stream))
             _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), C.byref(total), stream))
             self.total = int(total.value)
             # pass 2: store trajectories, the rebound log and the post-pass scalars
@@ -813,7 +818,10 @@ class RayPack2D:
         a = np.atleast_1d(np.asarray(a, dtype=np.float64))
         known = np.zeros(len(a), dtype=bool)
         if self._angle_set:
-            known |= np.isin(a, np.fromiter(self._angle_set, dtype=np.float64, count=len(self._angle_set)))
+            if len(a) <= 64:
+                known |= np.fromiter((x in self._angle_set for x in a.tolist()), dtype=bool, count=len(a))
+            else:
+                known |= np.isin(a, np.fromiter(self._angle_set, dtype=np.float64, count=len(self._angle_set)))
         for block in self._angle_blocks:
             pos = np.minimum(np.searchsorted(block, a), len(block) - 1)
             known |= block[pos] == a
@@ -841,7 +849,9 @@ class RayPack2D:
             fresh = ~self._known_angles(a)
             if not fresh.all():
                 cand, a = cand[fresh], a[fresh]
-        if len(a):
+        if 0 < len(a) <= 64:
+            self._angle_set.update(a.tolist())                  # a handful of rays (refine adds them one by one): the set
+        elif len(a):
             self._angle_blocks.append(a.copy() if rising else a[::-1].copy() if falling else np.sort(a))
         keep = cand
         if not len(keep):
