@@ -108,6 +108,14 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         o.reb_angle, o.reb_pos_x, o.reb_pos_z = reb_ang.data_ptr(), reb_px.data_ptr(), reb_pz.data_ptr()
         return o
 
+    summ = torch.empty(8, **f64)
+
+    def summarise(offsets):
+        """rt2d_fan_summary: [points, longest tile, log overflow, error-free rays, plot range x4] in one 64-byte read"""
+        _lib.check(L.rt2d_fan_summary(status.data_ptr(), rng.data_ptr(), None, n, offsets.data_ptr(), summ.data_ptr(), stream))
+        return summ.tolist()
+
+    sm = None
     room = 4096
     speculative = n_tiles * room * 64 * 16 <= (1 << 30)          # same policy as RayFan (ray-tracer_amd/rays.py)
     padded = (not speculative and n_tiles * room * 64 * 16 <= rays.PADDED_BYTES
@@ -125,8 +133,8 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         if ev: ev[3].record()
         exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=device)
         _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
-        longest, log_full = torch.stack((exact.diff().max(), (status == -2).any().to(torch.int64))).tolist()
-        done = longest <= room * 64 and not log_full
+        sm = summarise(exact)
+        done = sm[1] <= room * 64 and not sm[2]
         if not done:
             del X, Z
             tile_off = torch.empty(n_tiles + 1, dtype=torch.int64, device=device)
@@ -140,9 +148,9 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
                                      off0.data_ptr(), X0.data_ptr(), Z0.data_ptr(), None, stream))
         if ev: ev[3].record()
         _lib.check(L.rt2d_traj_layout(n_pts.data_ptr(), n, tile_off.data_ptr(), None, stream))
-        tot, longest, log_full = torch.stack((tile_off[-1], tile_off.diff().max(), (status == -2).any().to(torch.int64))).tolist()
-        if longest <= room * 64 and not log_full:
-            total = int(tot)
+        sm = summarise(tile_off)
+        if sm[1] <= room * 64 and not sm[2]:
+            total = int(sm[0])
             X, Z = torch.empty(total, **f64), torch.empty(total, **f64)
             _lib.check(L.rt2d_traj_compact(off0.data_ptr(), tile_off.data_ptr(), n, X0.data_ptr(), Z0.data_ptr(), None,
                                            X.data_ptr(), Z.data_ptr(), None, stream))
@@ -159,6 +167,7 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         _lib.check(L.rt2d_cast_write(handle, angles_dev.data_ptr(), n, src, C.byref(p), None, None, C.byref(with_log(out)),
                                      tile_off.data_ptr(), X.data_ptr(), Z.data_ptr(), None, stream))
         if ev: ev[3].record()
+        sm = summarise(tile_off)
     if ev: ev[4].record()
     # RT2D_BENCH_ONE_PASS=1: gain + binning in ONE pass over the trajectories (RayFan.heatmap_accumulate_stream) for big fans;
     # slower than the two kernels today (17.5 vs 15.1 ms per 1M rays), kept as the form that needs no gain array
@@ -170,15 +179,15 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
         _lib.check(L.rt2d_gain(handle, X.data_ptr(), Z.data_ptr(), tile_off.data_ptr(), n_pts.data_ptr(), C.byref(out), cap, n,
                                freq.data_ptr(), 1, total, G.data_ptr(), None, loss_ws.data_ptr(), stream))
     if ev: ev[5].record()
-    # plot range of the rays that did not fail (RayPack2D.add fold, origin included) -> heat-map shape
+    # plot range of the rays that did not fail (RayPack2D.add fold, origin included) -> heat-map shape: already in the
+    # summary read above; with several ranks one max-all-reduce of the four numbers (C1) and one more read
     okm = (status == 0)
-    big = torch.finfo(torch.float64).max
-    lo = torch.minimum(torch.where(okm, rng[:2], torch.full_like(rng[:2], big)).amin(dim=1), torch.zeros(2, **f64))
-    hi = torch.maximum(torch.where(okm, rng[2:], torch.full_like(rng[2:], -big)).amax(dim=1), torch.zeros(2, **f64))
-    ext = torch.cat((-lo, hi))                                                 # one collective, one device -> host read
     if collectives:
+        ext = summ[4:8].clone()
         parallel._all_reduce(ext, torch.distributed.ReduceOp.MAX)              # C1
-    ext = ext.cpu().numpy()
+        ext = ext.cpu().numpy()
+    else:
+        ext = np.array(sm[4:8])
     lo, hi = -ext[:2], ext[2:]
     shape = parallel.heatmap_shape(lo, hi, RES)
     H = torch.zeros(int(shape[0]) * int(shape[1]), **f64)

@@ -156,6 +156,16 @@ int32_t rt2d_cast_count(rt2d_env_t env, const double* angles, int64_t n, const d
  * total_out (host, may be NULL) receives tile_off[n_tiles]; when non-NULL the call synchronises the stream. */
 int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int64_t* total_out, void* stream);
 
+/* What the host needs to know about a finished cast, in one kernel and one 64-byte read (reference: the range fold
+ * of RayPack2D.add, ray.py:466-472; the rest has no counterpart -- it validates the single-pass layouts).
+ * status: device, n.  range: device, 4*n as in Rt2dRayOut (may be NULL).  ray_mask: device, n bytes, nonzero = count
+ * this ray (may be NULL = all).  tile_off: device, n_tiles+1 offsets of the EXACT layout from rt2d_traj_layout (may be
+ * NULL).  summary: device, 8 doubles: [0] tile_off[n_tiles], [1] elements of the longest tile, [2] 1 if any ray has
+ * RT2D_RAY_ERR_REBOUND_LOG, [3] rays with status 0 (and mask), [4..7] = (-min x, -min z, max x, max z) over those
+ * rays folded from the origin (all four >= 0), i.e. the plot range; one max-all-reduce of [4..7] merges ranks. */
+int32_t rt2d_fan_summary(const int32_t* status, const double* range, const uint8_t* ray_mask, int64_t n,
+                         const int64_t* tile_off, double* summary, void* stream);
+
 /* Same propagation, storing every point (reference: the np.insert at ray.py:192,216,236) in tile layout.
  * C (device, may be NULL) additionally receives the sound speed at every point (ray.py:273).
  * A tile never writes outside [tile_off[t], tile_off[t+1]): points beyond the tile's room are counted in n_pts but

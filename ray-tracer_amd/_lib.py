@@ -18,7 +18,7 @@ STOP_REASONS = [None, 'exit-xmin', 'exit-xmax', 'exit-zmin', 'exit-zmax', 'max-r
 RAY_OK, RAY_ERR_INTERP, RAY_ERR_REBOUND_LOG = 0, -1, -2
 
 EXPORTS = ['rt2d_last_error', 'rt2d_version', 'rt2d_env_create', 'rt2d_env_destroy', 'rt2d_env_surface_speed',
-           'rt2d_cast_count', 'rt2d_traj_layout', 'rt2d_cast_write', 'rt2d_traj_compact', 'rt2d_post', 'rt2d_gain', 'rt2d_dist',
+           'rt2d_cast_count', 'rt2d_traj_layout', 'rt2d_fan_summary', 'rt2d_cast_write', 'rt2d_traj_compact', 'rt2d_post', 'rt2d_gain', 'rt2d_dist',
            'rt2d_heatmap_accumulate', 'rt2d_heatmap_finalize', 'rt2d_cast_heatmap', 'rt2d_gain_heatmap', 'rt2d_rebound_loss']
 
 
@@ -96,6 +96,7 @@ def lib():
         'rt2d_env_surface_speed': [vp, C.POINTER(dbl)],
         'rt2d_cast_count': [vp, vp, i64, C.POINTER(dbl), C.POINTER(Rt2dParams), vp, vp, C.POINTER(Rt2dRayOut), vp],
         'rt2d_traj_layout': [vp, i64, vp, C.POINTER(i64), vp],
+        'rt2d_fan_summary': [vp, vp, vp, i64, vp, vp, vp],
         'rt2d_cast_write': [vp, vp, i64, C.POINTER(dbl), C.POINTER(Rt2dParams), vp, vp, C.POINTER(Rt2dRayOut),
                             vp, vp, vp, vp, vp],
         'rt2d_traj_compact': [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],

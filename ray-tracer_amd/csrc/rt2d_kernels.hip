@@ -786,6 +786,63 @@ __global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     
 }
 
 // copy every tile from a provisional (padded) layout into the exact one: within a tile both are [step][lane]
+// Everything the host needs to know about a finished cast in 8 doubles (RayPack2D.add's range fold ray.py:466-472 and
+// the checks behind the single-pass layouts): [0] points of the exact layout, [1] elements of its longest tile, [2] 1 if
+// a rebound log overflowed, [3] rays without error, [4..7] = (-min x, -min z, max x, max z) over those rays, folded
+// from the origin.  All maxima are over non-negative doubles, whose bit patterns order like the numbers.
+__global__ void __launch_bounds__(256) rt2d_fan_summary_kernel(const int32_t* status, const double* range, const uint8_t* ray_mask,
+                                                               int64_t n, const int64_t* tile_off, int64_t n_tiles, double* summary) {
+    double ext[4] = {0.0, 0.0, 0.0, 0.0};
+    double longest = 0.0, full = 0.0, n_ok = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const int st = status[r];
+        if (st == RT2D_RAY_ERR_REBOUND_LOG) full = 1.0;
+        if (st != RT2D_RAY_OK || (ray_mask && !ray_mask[r])) continue;
+        n_ok += 1.0;
+        if (range) {
+            const double lo_x = -range[r], lo_z = -range[n + r], hi_x = range[2 * n + r], hi_z = range[3 * n + r];
+            ext[0] = (lo_x > ext[0]) ? lo_x : ext[0];
+            ext[1] = (lo_z > ext[1]) ? lo_z : ext[1];
+            ext[2] = (hi_x > ext[2]) ? hi_x : ext[2];
+            ext[3] = (hi_z > ext[3]) ? hi_z : ext[3];
+        }
+    }
+    if (tile_off)
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += stride) {
+            const double len = (double)(tile_off[t + 1] - tile_off[t]);
+            longest = (len > longest) ? len : longest;
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double o = __shfl_xor(ext[k], off); ext[k] = (o > ext[k]) ? o : ext[k]; }
+        const double ol = __shfl_xor(longest, off); longest = (ol > longest) ? ol : longest;
+        const double of = __shfl_xor(full, off); full = (of > full) ? of : full;
+        n_ok += __shfl_xor(n_ok, off);
+    }
+    // the four waves of the block combine in LDS, then one set of atomics per block
+    __shared__ double s_part[4][7];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_part[wave][0] = longest; s_part[wave][1] = full; s_part[wave][2] = n_ok;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_part[wave][3 + k] = ext[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        double v = s_part[0][k];
+        for (int w = 1; w < 4; ++w) v = (k == 2) ? v + s_part[w][k] : ((s_part[w][k] > v) ? s_part[w][k] : v);
+        unsigned long long* bits = reinterpret_cast<unsigned long long*>(summary);
+        const int slot = 1 + k;                              // longest -> [1], full -> [2], n_ok -> [3], ext -> [4..7]
+        if (v > 0.0) {
+            if (k == 2) atomicAdd(&summary[slot], v);
+            else atomicMax(&bits[slot], (unsigned long long)__double_as_longlong(v));
+        }
+    }
+    if (tile_off && blockIdx.x == 0 && threadIdx.x == 0) summary[0] = (double)tile_off[n_tiles];
+}
+
 __global__ void __launch_bounds__(256) rt2d_compact_kernel(const int64_t* off_src, const int64_t* off_dst, int64_t n_tiles,
                                                            const double* X0, const double* Z0, const double* C0,
                                                            double* X1, double* Z1, double* C1) {
@@ -1823,6 +1880,21 @@ int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int
         HIP_OK(hipMemcpyAsync(total_out, tile_off + n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
     }
+    return 0;
+}
+
+int32_t rt2d_fan_summary(const int32_t* status, const double* range, const uint8_t* ray_mask, int64_t n,
+                         const int64_t* tile_off, double* summary, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!status || !summary) return fail("rt2d_fan_summary: null argument");
+    if (n < 0) return fail("rt2d_fan_summary: negative ray count");
+    HIP_OK(hipMemsetAsync(summary, 0, 8 * sizeof(double), stream));
+    if (n == 0) return 0;
+    const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(rt2d_fan_summary_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream,
+                       status, range, ray_mask, n, tile_off, n_tiles, summary);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 

@@ -188,9 +188,8 @@ class RayFan:
                 C0 = torch.empty(n_tiles * room * TILE, **f64) if store_c else None
                 cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
                 _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), None, stream))
-                # one device -> host read: total points, longest tile, "a rebound log overflowed"
-                tot, longest, log_full = torch.stack((self.tile_off[-1], self.tile_off.diff().max(),
-                                                      (self.status == _lib.RAY_ERR_REBOUND_LOG).any().to(torch.int64))).tolist()
+                # one kernel, one device -> host read: total points, longest tile, "a rebound log overflowed", plot range
+                tot, longest, log_full = self._summarise(self.tile_off, stream)
                 if longest <= room * TILE and not log_full:
                     total.value = tot
                     self.total = int(total.value)
@@ -217,7 +216,7 @@ class RayFan:
                     cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
                     exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
                     _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
-                    longest, log_full = torch.stack((exact.diff().max(), (self.status == _lib.RAY_ERR_REBOUND_LOG).any().to(torch.int64))).tolist()
+                    _, longest, log_full = self._summarise(exact, stream)
                     if longest <= room_p * TILE and not log_full:
                         self.tile_off, self._tile_off_exact = off0, exact
                         self.X, self.Z, self.Cpt = X0, Z0, C0
@@ -248,6 +247,16 @@ class RayFan:
             cast_write(out, self.rebound_cap, self.tile_off, self.X, self.Z, self.Cpt)
             self._out = out
             self.passes = 'count+store'
+
+    def _summarise(self, tile_off, stream):
+        """rt2d_fan_summary of the finished cast -> (total points, longest tile, rebound log overflowed); the whole
+        summary (with the plot range of the error-free rays) is kept for RayPack2D.add_fan."""
+        torch = _torch()
+        summ = torch.empty(8, dtype=torch.float64, device=self.device)
+        _lib.check(_lib.lib().rt2d_fan_summary(self.status.data_ptr(), self.range.data_ptr(), None, self.n,
+                                               tile_off.data_ptr(), summ.data_ptr(), stream))
+        self._summary = summ.tolist()
+        return int(self._summary[0]), int(self._summary[1]), bool(self._summary[2])
 
     # -- scalars produced on demand ---------------------------------------------------------------
     def _lazy_scalars(self):
@@ -860,7 +869,10 @@ class RayPack2D:
         self.rays._add_segment(fan, keep)
         self.n_rays += len(keep)
         self.n_angles += len(keep)
-        if 'range' in fan._host or len(keep) < 4096:
+        summ = getattr(fan, '_summary', None)
+        if summ is not None and len(keep) == fan.n and int(summ[3]) == fan.n:
+            lo_hi = np.array([-summ[4], -summ[5], summ[6], summ[7]])     # every ray kept and error-free: the cast's own fold
+        elif 'range' in fan._host or len(keep) < 4096:
             rng = fan.host('range')
             lo_hi = np.array([rng[0, keep].min(), rng[1, keep].min(), rng[2, keep].max(), rng[3, keep].max()])
         else:                                                    # big fan: fold on the device, 4 numbers come back
