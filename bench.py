@@ -401,7 +401,7 @@ def main():
             'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': traffic_src, 'algorithmic_bytes': steps_rank * BYTES_PER_STEP,
-                         'note': '999 rays = 16 wavefronts on 256 CUs: latency-bound by construction; see large_fan',
+                         'note': '999 rays = 250 wavefronts of 4 rays, one per CU: bound by the dependent-instruction latency of a lone wave (DESIGN.md section 6); see large_fan for the full chip',
                          'fp64_valu_frac': steps_rank * FLOP_PER_STEP / (store_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
         }
 
