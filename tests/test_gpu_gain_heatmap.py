@@ -284,3 +284,45 @@ def test_heatmaps_for_an_array_of_frequencies(rt, orc):
         assert np.array_equal(np.isfinite(maps[f]), fin)
         assert np.abs(maps[f] - plot_ref)[fin].max() < 1e-11
     assert np.nanmax(np.abs(maps[freqs[0]] - maps[freqs[1]])) > 1e-3           # the maps do depend on the frequency
+
+
+@pytest.mark.gpu
+def test_extreme_gains_take_the_pow_path_in_both_kernels(rt):
+    """Gains beyond +-3000 dB (a rebound coefficient that underflowed to 0 gives -inf) leave the 2^x shortcut for the
+    reference's two pows (ray.py:317, simulation.py:129): (10^(G/10))^-0.1 is inf / 0 there.  The tile kernel keeps
+    that path out of its loop, the general kernel inline: both must agree with NumPy's own arithmetic."""
+    import torch
+    g = common.load('c2_fan999')
+    fan, env = _cast(rt, g)
+    fan.populate(1.)
+    G = fan.G[1.]
+    rng = np.random.default_rng(5)
+    pick = torch.from_numpy(rng.random(G.numel()) < 0.02).to(G.device)
+    vals = torch.from_numpy(rng.choice([-np.inf, -5000., -3000., 3000., 4000., -3200.5], G.numel())).to(G.device)
+    fan.G[1.] = torch.where(pick, vals, G)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    sim.raypacks['main'].add_fan(fan)
+    Hf, _ = sim.heatmap_full(resolution=[50, 25], fast=True, hint=True)
+    Hg, _ = sim.heatmap_full(resolution=[50, 25], fast=False)
+    Hf, Hg = Hf.cpu().numpy(), Hg.cpu().numpy()
+    assert np.isinf(Hg).any() and (Hg[np.isfinite(Hg)] > 0).any()
+    assert np.array_equal(np.isinf(Hf), np.isinf(Hg))
+    fin = np.isfinite(Hg)
+    assert np.abs(Hf[fin] - Hg[fin]).max() <= 1e-12 * np.abs(Hg[fin]).max()
+    # one ray against NumPy: last write wins per cell, value by the two pows
+    i = int(np.nonzero(fan.host('status') == 0)[0][3])
+    ray = rt.Ray2D._from_fan(fan, i)
+    Gi = fan.G[1.][fan.tile_off[i // 64] + i % 64::64][:ray.steps].cpu().numpy()
+    mask = torch.zeros(fan.n, dtype=torch.uint8, device=G.device); mask[i] = 1
+    shape = Hg.shape
+    H1 = torch.zeros(shape[0] * shape[1], dtype=torch.float64, device=G.device)
+    fan.heatmap_accumulate(H1, [50, 25], shape, freq=1., ray_mask=mask, fast=True, hint=True)
+    want = np.zeros(shape)
+    with np.errstate(all='ignore'):
+        v = np.power(np.power(10., Gi / 10), -0.1)
+    ix, iz = ray.XZ[:, 0].astype(int) // 50, ray.XZ[:, 1].astype(int) // -25
+    want[ix, iz] = v
+    got = H1.cpu().numpy().reshape(shape)
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    f = np.isfinite(want)
+    assert np.abs(got[f] - want[f]).max() <= 1e-12 * max(1.0, np.abs(want[f]).max())
