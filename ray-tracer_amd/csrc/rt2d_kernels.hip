@@ -536,7 +536,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         if (POST >= 1) slope_max = vmax(slope_max, fabs(dx_z));
         {
             double s = p.dx_max;
-            if (__any(steep)) {                  // wave-uniform: a wave of shallow rays never pays for the division
+            if (__builtin_expect(__any(steep), 0)) {     // wave-uniform and out of line: the long, shallow rays that set a
+                                                         // small fan's time fall through without the division or a taken branch
                 const double ss = p.dz_max / fabs(dx_z);
                 if (steep) s = ss;
             }
@@ -688,7 +689,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         const double dzr = z - rz[0];
         c = rt2d_quad_of(rz, dzr, 0);
         const double dz_c = rt2d_quad_of(rz, dzr, 1);
-        if (FULL || (WRITE && pc)) c_pt = c;
+        if (FULL || (WRITE && a.C != nullptr)) c_pt = c;
         if (POST >= 1) {
             min_x = vmin(min_x, x); max_x = vmax(max_x, x);        // bare instructions: see vmax / vmin above
             min_z = vmin(min_z, z); max_z = vmax(max_z, z);
@@ -697,7 +698,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         if (WRITE && __builtin_expect(n_pts < room, 1)) {
             px += RT2D_WAVE; pz += RT2D_WAVE;
             *px = x; *pz = z;
-            if (pc) { pc += RT2D_WAVE; *pc = c; }
+            if (__builtin_expect(a.C != nullptr, 0)) { pc += RT2D_WAVE; *pc = c; }     // uniform test: no per-lane branch to skip
         }
         n_pts += 1;
         if (FUSE) binner.point(a.bin, x, z, g_pt, lane);
