@@ -275,6 +275,10 @@ __device__ __forceinline__ double rt2d_div_by_const(double a, double b, double y
     return fma(r1, y, q1);
 }
 
+// Wave votes straight from the compare's lane mask (the library forms go through a 0/1 register and a second compare)
+__device__ __forceinline__ bool rt2d_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool rt2d_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 // a / 1000 of the gain integrand (ray.py:346): five FMAs instead of the 13-instruction division (with its quarter-rate
 // reciprocal) in every (point, frequency) of the gain loops; outside the range the identity is tested on, divide.
 __device__ __forceinline__ double rt2d_div_1000(double a) {
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         if (POST >= 1) slope_max = vmax(slope_max, fabs(dx_z));
         {
             double s = p.dx_max;
-            if (__builtin_expect(__any(steep), 0)) {     // wave-uniform and out of line: the long, shallow rays that set a
+            if (__builtin_expect(rt2d_any(steep), 0)) {     // wave-uniform and out of line: the long, shallow rays that set a
                                                          // small fan's time fall through without the division or a taken branch
                 const double ss = p.dz_max / fabs(dx_z);
                 if (steep) s = ss;
@@ -584,7 +588,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         bool final_pt = false;                 // the point about to be accepted is the ray's last (max-rebounds)
         // (branch hints: a wave alone on its CU pays an instruction-fetch stall at every taken branch, so the common
         // step should be laid out as straight-line code)
-        if (__builtin_expect(__any(general), 0)) if (general) {
+        if (__builtin_expect(rt2d_any(general), 0)) if (general) {
             if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
             // clipped in x is still inside in z; the clipped point is NOT appended
@@ -708,7 +712,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         // k1/k0 (ray.py:243).  In a wave whose rays all took a plain dx_max step, k0 is +-dx_max exactly and the quotient
         // comes from rt2d_div_by_const (same bits); any other wave divides.
         const bool plain = !steep & !general & (fabs(kx) == p.dx_max) & (fabs(kz) >= 1e-250);
-        if (__builtin_expect(__all(plain), 1)) {
+        if (__builtin_expect(rt2d_all(plain), 1)) {
             const double q = rt2d_div_by_const(kz, p.dx_max, a.inv_dx_max);
             dx_z = (kx < 0.0) ? -1 * q : q;
         } else {
