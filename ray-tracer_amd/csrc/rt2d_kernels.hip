@@ -2109,7 +2109,7 @@ int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cuto
     HIP_OK(hipMemsetAsync(scratch, 0, 2 * sizeof(double), stream));
     const int block = 256;
     const int64_t blocks = (size + block - 1) / block;
-    hipLaunchKernelGGL(rt2d_hm_max_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(block), 0, stream,
+    hipLaunchKernelGGL(rt2d_hm_max_kernel, dim3((unsigned)(blocks < 128 ? blocks : 128)), dim3(block), 0, stream,     // few waves: each ends in an atomic on one word
                        H, size, (unsigned long long*)scratch);
     hipLaunchKernelGGL(rt2d_hm_finalize_kernel, dim3((unsigned)blocks), dim3(block), 0, stream,
                        H, nx, nz, cutoff, reduction_power, (const unsigned long long*)scratch, out);
