@@ -449,6 +449,31 @@ def main():
             # the counting pass stores nothing: stepping alone, the FP64 vector figure of the cast kernel
             'count_pass_steps_per_s': sf / (stf['cast_count'] * 1e-3),
             'count_pass_fp64_valu_frac': sf * FLOP_PER_STEP / (stf['cast_count'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
+        # the same fan over a bathymetry cut (BASELINE configs 3 / 5: the floor is a table cut out of an ESRI grid;
+        # the reference's data/asc file is absent, so the synthetic grid of the parity fixtures stands in)
+        asc = os.path.join(ROOT, 'tests', 'golden', 'synth_bathy.asc')
+        if os.path.exists(asc):
+            bmap = rt.Map.from_asc(asc)
+            b0, b1 = (3.05, 41.7), (3.9, 41.75)
+            length = float(bmap.cut_length(b0, b1))
+            env_b = rt.Environment2D(bmap.floor_table(b0, b1, npoints=751), (np.array([0., length]), np.array([0., 0.])),
+                                     np.array([0., -2501.]), np.array([length, 1.]))
+            env_b.device_handle(device.index)
+            src_b = np.array([0., -50.])
+            one_step(rt, torch, env_b, src_b, big_angles, device=device)
+            stages_b = Stages(torch)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(args.large_steps):
+                _, n_pts_b, status_b, hm_b = one_step(rt, torch, env_b, src_b, big_angles, stages=stages_b, device=device)
+            torch.cuda.synchronize(); dtb = time.perf_counter() - t0
+            sb = ray_steps_of(n_pts_b, status_b)
+            result['large_fan_bathymetry'] = {
+                'rays': nL, 'floor': 'Map.from_asc(tests/golden/synth_bathy.asc).floor_table((3.05, 41.7), (3.9, 41.75), 751): '
+                                     f'{length / 1e3:.1f} km cut, depths {float(env_b.floor(np.linspace(0, length, 751)).max()):.0f} '
+                                     f'to {float(env_b.floor(np.linspace(0, length, 751)).min()):.0f} m',
+                'ray_steps': sb, 'rays_with_error_status': int((status_b != 0).sum().item()),
+                'value': sb * args.large_steps / dtb, 'unit': 'ray-steps/s', 's_per_heatmap': dtb / args.large_steps,
+                'stage_ms': stages_b.summary(), 'heatmap_shape': list(hm_b.shape)}
         del big_angles
     if rank == 0 and world == 1:
         # "raypower cutoff=0.5" read the other way (SURVEY trap 2): rays END when their power falls below the cutoff --
