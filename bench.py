@@ -249,6 +249,29 @@ def pmc_traffic(large):
     return (cand[-1] if large else cand[0])[1]['hbm_bytes'], os.path.relpath(files[-1], ROOT)
 
 
+def pmc_binning():
+    """Per-launch HBM bytes and L2 atomic requests of the two binning kernels on the 1M-ray fan, from the newest committed
+    PMC passes (profiles/r*/*_traffic.json, *_counters.json: FETCH_SIZE / WRITE_SIZE / TCC_ATOMIC_sum passes of this command)."""
+    import glob
+    out = {'hbm_bytes': None, 'atomics': None, 'source': None}
+    tf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*_traffic.json')))
+    cf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*_counters.json')))
+    def big(k, names):
+        rows = [v for name, v in k.items() if name.split('|')[0] in names and int(name.split('grid=')[1].split('|')[0]) >= (1 << 20)]
+        return rows
+    names = ('rt2d_heatmap_fast_kernel<1>', 'rt2d_heatmap_kernel')
+    if tf:
+        rows = big(json.load(open(tf[-1]))['kernels'], names)
+        if rows and all(r.get('hbm_bytes') is not None for r in rows):
+            out['hbm_bytes'] = sum(r['hbm_bytes'] for r in rows)
+            out['source'] = os.path.relpath(tf[-1], ROOT)
+    if cf:
+        rows = big(json.load(open(cf[-1]))['kernels'], names)
+        if rows and all('TCC_ATOMIC_sum' in r for r in rows):
+            out['atomics'] = sum(r['TCC_ATOMIC_sum'] for r in rows)
+    return out
+
+
 def one_step_fused(rt, torch, env, source, angles_dev, ev=None, device=None):
     """The same product, trajectories never stored: count pass (per-ray scalars, plot range) -> fused cast+gain+binning
     for the rays it can bin exactly, stored path for the others -> normalise.  This is Simulation2D.cast(store=False)
@@ -427,6 +450,16 @@ def main():
                          'traffic_source': traffic_src_l, 'algorithmic_bytes': sl * BYTES_PER_STEP,
                          'fp64_valu_frac': sl * FLOP_PER_STEP / (stl['cast_store'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
         }
+        if nL == (1 << 20):
+            pb = pmc_binning()
+            t_bin = stl['heatmap'] * 1e-3
+            result['large_fan']['binning'] = {
+                'kernels': 'rt2d_heatmap_fast_kernel (tile) + rt2d_heatmap_kernel (general)', 'ms': stl['heatmap'],
+                'algorithmic_bytes': sl * 24,                    # x, z, gain of every point read once
+                'achieved_GBps_algorithmic': sl * 24 / t_bin / 1e9, 'frac_of_hbm_peak': sl * 24 / t_bin / 1e9 / HBM_PEAK_GBS,
+                'hbm_bytes_pmc': pb['hbm_bytes'], 'l2_atomics_pmc': pb['atomics'],
+                'atomics_per_s': None if pb['atomics'] is None else pb['atomics'] / t_bin,
+                'points_per_atomic': None if not pb['atomics'] else sl / pb['atomics'], 'pmc_source': pb['source']}
         # the fused pipeline on the same fan (no trajectory in HBM)
         _, hm_f = one_step_fused(rt, torch, env, source, big_angles, device=device)
         recs = []
