@@ -177,3 +177,19 @@ def test_half_offset_floor_division():
         t = t[(t > -2 ** 31) & (t < 2 ** 31)]
         q = np.floor((t.astype(np.float64) + 0.5) * inv).astype(np.int64)
         assert np.array_equal(q, t // b), b
+
+
+def test_ctypes_signatures_follow_the_header(rt):
+    """Every prototype of include/rt2d.h has a ctypes signature of the same arity in ray-tracer_amd/_lib.py (the
+    definitions themselves are checked against the header by the compiler: csrc includes it inside extern "C")."""
+    header = open(os.path.join(ROOT, 'include', 'rt2d.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    L = rt._lib.lib()
+    seen = 0
+    for m in re.finditer(r'\b(?:int32_t|const char\*)\s+(rt2d_\w+)\s*\(([^;]*?)\)\s*;', header, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ('void', '') else len(args.split(','))
+        at = getattr(L, name).argtypes
+        assert at is not None and len(at) == n, (name, n, at)
+        seen += 1
+    assert seen == len(rt._lib.EXPORTS)
