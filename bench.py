@@ -428,6 +428,33 @@ def main():
                          'fp64_valu_frac': steps_rank * FLOP_PER_STEP / (store_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
         }
 
+    # N > 1: the 1M-ray fan of the single-GPU block below, SHARDED over the ranks (strong scaling: north_star's "1M-ray
+    # heat map on 8 GPUs").  Rays are dealt in blocks of 64 (one tile) round-robin, so every rank sees the whole angular
+    # range; C1 / C2 as in the headline step.  Timed like the headline: barrier, K steps, barrier, max over ranks.
+    if args.large_rays > 0 and world > 1:
+        nL = args.large_rays
+        tiles = np.arange(rank, (nL + 63) // 64, world)
+        jj = (tiles[:, None] * 64 + np.arange(64)[None, :]).reshape(-1)
+        jj = jj[jj < nL]
+        shard_angles = torch.from_numpy(-(jj + 1) * (0.999 / nL)).to(device)
+        one_step(rt, torch, env, source, shard_angles, collectives=True, device=device)
+        stages_s = Stages(torch)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(args.large_steps):
+            _, n_pts_s, status_s, hm_s = one_step(rt, torch, env, source, shard_angles, stages=stages_s, collectives=True, device=device)
+        barrier(); dts = time.perf_counter() - t0
+        from ray_tracer_amd import parallel
+        ts = torch.tensor([dts, float(ray_steps_of(n_pts_s, status_s))], dtype=torch.float64, device=device)
+        ts_max = parallel._all_reduce(ts.clone(), dist.ReduceOp.MAX)
+        ts_sum = parallel._all_reduce(ts.clone(), dist.ReduceOp.SUM)
+        if rank == 0:
+            dts = float(ts_max[0].item())
+            result['large_fan_sharded'] = {
+                'rays_total': nL, 'rays_per_gpu': int(len(jj)), 'scaling': 'strong', 'ray_steps_total': float(ts_sum[1].item()),
+                'value': float(ts_sum[1].item()) * args.large_steps / dts, 'unit': 'ray-steps/s',
+                's_per_heatmap': dts / args.large_steps, 'stage_ms_rank0': stages_s.summary(), 'heatmap_shape': list(hm_s.shape)}
+        del shard_angles
+
     # the same pipeline where the GPU is full (single-GPU block, rank 0 only prints it)
     if args.large_rays > 0 and world == 1:
         nL = args.large_rays
