@@ -251,6 +251,19 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
 int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,
                   const double* target, double* dist, void* stream);
 
+/* Eigenray products (reference: Ray2D.gen_filter ray.py:382-405 with closest_step_to_point ray.py:371-373), for
+ * n_sel rays at once: the stored point closest to `target` (first of equal distances, as np.argmin), the travel time
+ * T[step] + d / c(z_avg) and, per frequency, the transmittance 10^((G[step] + G_add) / 10) with
+ * G_add = -alpha(f, z_avg) / 1000 * d over the straight residual d from that point to the target.
+ * T: device, tile layout, from rt2d_post.  G: device array of n_freqs device pointers, each one frequency's gain in
+ * tile layout (rt2d_gain).  ray_ids: device, n_sel ray indices (NULL = rays 0..n_sel-1).  target: host, 2 doubles.
+ * freqs: device, n_freqs.  step_out (device int32, n_sel), T_target (device, n_sel), Tmult (device, n_freqs * n_sel,
+ * [f * n_sel + i]). */
+int32_t rt2d_target_products(rt2d_env_t env, const double* X, const double* Z, const double* T, const double* const* G,
+                             const int64_t* tile_off, const int32_t* n_pts, const int32_t* ray_ids, int64_t n_sel,
+                             const double* target, const double* freqs, int32_t n_freqs,
+                             int32_t* step_out, double* T_target, double* Tmult, void* stream);
+
 /* Heat-map accumulation (reference: simulation.py:120-131 + functions.py:12-19): for every ray, the
  * value 10^(G/10)^-0.1 of the LAST point falling in each cell (x//res_x, z//-res_z) is added to H.
  * The cell arithmetic is the reference's integer arithmetic: trunc toward zero, then floor division, then the

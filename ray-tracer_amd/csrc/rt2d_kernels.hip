@@ -1287,6 +1287,57 @@ __global__ void __launch_bounds__(256) rt2d_dist_kernel(const double* X, const d
     dist[r] = tt.dist(tx, tz, np, mn, mx);
 }
 
+// Eigenray products (Ray2D.gen_filter, ray.py:382-405): per ray the stored point closest to the target (first of the
+// minimal distances, as np.argmin), the straight-line residual to the target, and from them the travel time to the
+// target and the transmittance 10^(G/10) at every frequency.  One wave per ray: lanes share the points for the
+// arg-min, then take one frequency each.
+struct TargetArgs {
+    DevEnv env; const double* blob;
+    const double* X; const double* Z; const double* T; const double* const* G;     // G: F device pointers, tile layout
+    const int64_t* tile_off; const int32_t* n_pts; const int32_t* ray_ids; int64_t n_sel;
+    double tx, tz; const double* freqs; int32_t n_freqs;
+    int32_t* step_out; double* T_target; double* Tmult;                             // Tmult[f * n_sel + i]
+};
+
+__global__ void __launch_bounds__(64) rt2d_target_products_kernel(const TargetArgs a) {
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t r = a.ray_ids ? (int64_t)a.ray_ids[i] : i;
+    const int np = a.n_pts[r];
+    const int64_t base = a.tile_off[r >> 6] + (r & 63);
+    double best = INFINITY; int best_s = 0x7fffffff;
+    for (int s = lane; s < np; s += RT2D_WAVE) {
+        const int64_t o = base + (int64_t)s * RT2D_WAVE;
+        const double dx = a.tx - a.X[o], dz = a.tz - a.Z[o];
+        const double d = sqrt(dx * dx + dz * dz);                                    // ray.py:372
+        if (d < best) { best = d; best_s = s; }                                          // strict: the first minimum stays
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(best, off); const int os = __shfl_xor(best_s, off);
+        if (os != 0x7fffffff && (best_s == 0x7fffffff || od < best || (od == best && os < best_s))) { best = od; best_s = os; }
+    }
+    if (best_s == 0x7fffffff) best_s = 0;                                            // no finite distance at all
+    const int64_t o = base + (int64_t)best_s * RT2D_WAVE;
+    const double px = a.X[o], pz = a.Z[o];
+    const double ddx = a.tx - px, ddz = a.tz - pz;
+    const double d_target = sqrt(ddx * ddx + ddz * ddz);                             // np.linalg.norm(target - p)
+    const double z_avg = (a.tz + pz) / 2;
+    if (lane == 0) {
+        a.step_out[i] = best_s;
+        a.T_target[i] = a.T[o] + d_target / rt2d_eval_c(a.blob, a.env.cz, z_avg);    // ray.py:403-404
+    }
+    const double* gtab = a.blob + a.env.gain_off;
+    double rec[20];
+    rt2d_lookup<19>(gtab, a.env.absorb, z_avg, rec);
+    const double dz = z_avg - rec[0];
+    for (int f = lane; f < a.n_freqs; f += RT2D_WAVE) {
+        const double fk = a.freqs[f] / 1000;
+        const double G_add = -1 * rt2d_alpha(rec, dz, fk * fk) / 1000 * d_target;    // ray.py:398
+        const double G_target = a.G[f][o] + G_add;
+        a.Tmult[(int64_t)f * a.n_sel + i] = pow(10.0, G_target / 10);                 // ray.py:400
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // heat map accumulation: one wave per ray; LDS hash "cell -> last step in that cell"
 #define HM_EMPTY 0xffffffffffffffffull
@@ -2050,6 +2101,24 @@ int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, con
     const int block = (n <= 64 * 512) ? 64 : 256;
     hipLaunchKernelGGL(rt2d_dist_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, (hipStream_t)stream,
                        X, Z, tile_off, n_pts, n, target[0], target[1], dist);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_target_products(rt2d_env_t env, const double* X, const double* Z, const double* T, const double* const* G,
+                             const int64_t* tile_off, const int32_t* n_pts, const int32_t* ray_ids, int64_t n_sel,
+                             const double* target, const double* freqs, int32_t n_freqs,
+                             int32_t* step_out, double* T_target, double* Tmult, void* stream) {
+    if (!env || !X || !Z || !T || !tile_off || !n_pts || !target || !step_out || !T_target)
+        return fail("rt2d_target_products: null argument");
+    if (n_freqs < 0 || (n_freqs > 0 && (!G || !freqs || !Tmult))) return fail("rt2d_target_products: frequencies need G, freqs and Tmult");
+    if (n_sel <= 0) return n_sel == 0 ? 0 : fail("rt2d_target_products: negative ray count");
+    if (n_sel > 0x7fffffff) return fail("rt2d_target_products: too many rays for one launch");
+    TargetArgs a; memset(&a, 0, sizeof a);
+    a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.T = T; a.G = G; a.tile_off = tile_off; a.n_pts = n_pts;
+    a.ray_ids = ray_ids; a.n_sel = n_sel; a.tx = target[0]; a.tz = target[1]; a.freqs = freqs; a.n_freqs = n_freqs;
+    a.step_out = step_out; a.T_target = T_target; a.Tmult = Tmult;
+    hipLaunchKernelGGL(rt2d_target_products_kernel, dim3((unsigned)n_sel), dim3(RT2D_WAVE), 0, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -305,6 +305,10 @@ class EigenraySim2D(Simulation2D):
         """Per ray of the pack, in increasing angle: travel time to the target and transmittance at every frequency
         (Ray2D.gen_filter, ray.py:382-405).  Returns (angles (n,), T_target (n,), Tmult_target (n, F))."""
         raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
+        if kwargs.get('batched', True):
+            out = self._target_products_batched(raypack, freqs)
+            if out is not None:
+                return out
         angles_sorted = np.sort(list(raypack.angles.keys()))
         T_t, Tm_t = [], []
         for angle in angles_sorted:
@@ -314,6 +318,43 @@ class EigenraySim2D(Simulation2D):
             T_t.append(T_target)
             Tm_t.append(Tmult_target)
         return angles_sorted, np.asarray(T_t, dtype=np.float64), np.asarray(Tm_t, dtype=np.float64)
+
+    def _target_products_batched(self, raypack, freqs):
+        """target_products for packs made of whole-fan segments whose rays carry exactly these frequencies: one
+        rt2d_target_products launch per fan (one wave per ray) instead of a host loop over rays and frequencies.
+        Returns None when the pack does not qualify (loose rays, rays populated at other frequencies too)."""
+        torch = _torch()
+        segs = raypack.rays._segments
+        if not segs or any(fan is None for fan, _ in segs):
+            return None
+        fl = sorted(dict.fromkeys(freqs))
+        ang, T_all, Tm_all = [], [], []
+        tgt = (C.c_double * 2)(float(self.target[0]), float(self.target[1]))
+        for fan, idx in segs:
+            if any(f not in fl for f in fan.G_end):
+                return None                               # gen_filter uses every frequency a ray has: leave it to the loop
+            fan.populate(*fl)
+            if any(f not in fan.G for f in fl):
+                return None
+            T = fan.post()['T']
+            with torch.cuda.device(fan.device):
+                ptrs = torch.tensor([fan.G[f].data_ptr() for f in fl], dtype=torch.int64, device=fan.device)
+                fr = torch.tensor(fl, dtype=torch.float64, device=fan.device)
+                ids = torch.as_tensor(np.asarray(idx, dtype=np.int32), device=fan.device)
+                k = len(idx)
+                step = torch.empty(k, dtype=torch.int32, device=fan.device)
+                T_t = torch.empty(k, dtype=torch.float64, device=fan.device)
+                Tm = torch.empty((len(fl), k), dtype=torch.float64, device=fan.device)
+                _lib.check(_lib.lib().rt2d_target_products(
+                    self.env.device_handle(fan.device.index), fan.X.data_ptr(), fan.Z.data_ptr(), T.data_ptr(), ptrs.data_ptr(),
+                    fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), ids.data_ptr(), k, tgt, fr.data_ptr(), len(fl),
+                    step.data_ptr(), T_t.data_ptr(), Tm.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            ang.append(np.asarray(fan.angles, dtype=np.float64)[np.asarray(idx, dtype=np.int64)])
+            T_all.append(T_t.cpu().numpy())
+            Tm_all.append(Tm.cpu().numpy().T)
+        ang, T_all, Tm_all = np.concatenate(ang), np.concatenate(T_all), np.concatenate(Tm_all, axis=0)
+        order = np.argsort(ang, kind='stable')
+        return ang[order], T_all[order], Tm_all[order]
 
     def get_filter_NEW(self, *freqs, **kwargs):
         """Filter that turns an emitted signal into the signal received at the target: every eigenray contributes the

@@ -54,3 +54,31 @@ def test_eigenray_filter_vs_reference(rt):
     sr, out = filt(float(g['sample_rate']), g['signal'])
     assert sr == float(g['sample_rate']) and out.shape == g['filtered'].shape
     assert np.abs(out - g['filtered']).max() < 1e-9 * np.abs(g['filtered']).max()
+
+
+@pytest.mark.gpu
+def test_target_products_batched_equals_the_per_ray_loop(rt):
+    """rt2d_target_products (one wave per ray: closest stored point, residual time and gain to the target)
+    against the host loop over Ray2D.gen_filter, which is the reference's own sequence (ray.py:382-405) and is pinned by
+    the tests_2.ipynb numbers: same closest steps, same travel times, transmittances to 1e-11."""
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    target = np.array([30000., -400.])
+    sim = rt.EigenraySim2D(env, g['fan_source'], target, 40, 20, n_rays_scan=4000, scan_angle_min=-0.9, scan_angle_max=-0.01,
+                           dx_max=50., dz_max=25.)
+    freqs = [1., 250., 5000., 20000.]
+    a1, T1, M1 = sim.target_products(*freqs, batched=True)
+    a0, T0, M0 = sim.target_products(*freqs, batched=False)
+    assert len(a1) >= 40 and np.array_equal(a1, a0)
+    assert M1.shape == M0.shape == (len(a1), len(freqs))
+    assert np.abs(T1 - T0).max() <= 1e-13 * np.abs(T0).max()
+    assert np.array_equal(M1 == 0, M0 == 0)
+    nz = M0 != 0
+    assert (np.abs(M1[nz] - M0[nz]) / M0[nz]).max() < 1e-11
+    # the closest step itself, for a few rays
+    pack = sim.raypacks[sim.pack_default]
+    for ray in list(pack.rays)[:5]:
+        s = ray.closest_step_to_point(target)
+        T_host, _ = ray.gen_filter(target)
+        k = int(np.nonzero(a1 == ray.angle)[0][0])
+        assert abs(T1[k] - T_host) <= 1e-13 * abs(T_host), (s, T1[k], T_host)
