@@ -124,8 +124,14 @@ __device__ __forceinline__ double rt2d_heat_val_pows(double g) {
     double tmult = pow(10.0, g / 10);
     return pow(tmult, -0.1);
 }
+// An infinite gain needs no pow either: 10^(-inf/10) = 0 and 0^-0.1 = inf; 10^(inf/10) = inf and inf^-0.1 = 0.  It is the
+// common case at high frequency, where the surface coefficient exp(-2 (k h sin a)^2) underflows to 0 at the first
+// surface rebound and every later point of the ray carries G = -inf (ray.py:350-362).
+__device__ __forceinline__ bool rt2d_heat_val_is_inf(double g) { return fabs(g) == INFINITY; }
+__device__ __forceinline__ double rt2d_heat_val_of_inf(double g) { return (g < 0.0) ? INFINITY : 0.0; }
 __device__ __forceinline__ double rt2d_heat_val(double g) {
     if (rt2d_heat_val_is_plain(g)) return rt2d_heat_val_plain(g);
+    if (rt2d_heat_val_is_inf(g)) return rt2d_heat_val_of_inf(g);
     return rt2d_heat_val_pows(g);
 }
 
@@ -1462,6 +1468,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
                 if (fresh) {
                     cell = ix * nz + iz;
                     if (__builtin_expect(rt2d_heat_val_is_plain(gs[u]), 1)) val = rt2d_heat_val_plain(gs[u]);   // ray.py:317, simulation.py:129
+                    else if (rt2d_heat_val_is_inf(gs[u])) val = rt2d_heat_val_of_inf(gs[u]);
                     else { fresh = false; late |= 1u << u; late_cell[u] = cell; }
                 }
             }
