@@ -1357,6 +1357,7 @@ struct HeatArgs {
     HeatGeom geo; int64_t nx, nz;
     double* H; int64_t* n_dropped; int32_t cap;     // cap: hash slots per ray, power of two
     int32_t cell_cap;                               // points per ray whose cells are cached in LDS
+    int32_t split;                                  // tile kernel: waves per tile, each walking a range of rows
 };
 
 // Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
@@ -1370,9 +1371,14 @@ struct HeatArgs {
 #endif
 template <int MW>     // 64-bit mask words per lane: rows nz <= 64 * MW
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
-    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x / RT2D_WAVE) + (threadIdx.x / RT2D_WAVE);
+    // Fans of 10^4..10^5 rays have too few tiles to give a SIMD more than one wave, and then the kernel's time is the
+    // length of one wave's walk.  Such a tile is walked by `split` waves, each taking a contiguous range of ROWS (see
+    // "rows of this wave" below); tiles with unchecked rays are walked whole by their first wave.
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x / RT2D_WAVE) + (threadIdx.x / RT2D_WAVE);
     const int lane = threadIdx.x & 63;
     const int64_t n_tiles = (a.n + RT2D_WAVE - 1) / RT2D_WAVE;
+    const int64_t tile = wave_id / a.split;
+    const int seg = (int)(wave_id % a.split);
     if (tile >= n_tiles) return;
     const int64_t r = tile * RT2D_WAVE + lane;
     const uint8_t flags = (r < a.n) ? (a.ray_mask ? a.ray_mask[r] : (uint8_t)1) : (uint8_t)0;
@@ -1393,7 +1399,14 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     // has |x|, |z| < 2^31 (shape * resolution below that), so the 32-bit cell arithmetic decides "inside the map" exactly.
     bool ok = true;
     int prev_ix = INT32_MIN;
-    const int t_check = __all(hinted || !mine) ? 0 : tmax;
+    // A shared tile cannot run the point-by-point check (its verdict would have to cross waves): if some of its rays are
+    // vouched for, the others go straight to the general kernel, which takes any ray; a tile without a single vouched-for
+    // ray (the caller gave no hints) is checked and walked whole by its first wave.
+    const bool send = a.split > 1 && __any(hinted) && mine && !hinted;
+    const bool all_hinted = __all(hinted || !mine || send);
+    if (!all_hinted && seg > 0) return;
+    const bool whole = a.split == 1 || !all_hinted;
+    const int t_check = all_hinted ? 0 : tmax;
     for (int s0 = 0; s0 < t_check; s0 += HM_UNROLL) {
         double xs[HM_UNROLL], zs[HM_UNROLL];
 #pragma unroll
@@ -1414,7 +1427,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     }
     // rays for the general kernel: one counter update per wave, and the rays of a tile stay together in the list (that
     // kernel's lines are shared by neighbouring rays, see its item mapping)
-    const bool queued = !ok && !hinted;
+    const bool queued = send ? seg == 0 : (!ok && !hinted);
     const unsigned long long qmask = __ballot(queued);
     if (qmask) {
         const int leader = __ffsll((long long)qmask) - 1;
@@ -1427,15 +1440,48 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             last = 0;
         }
     }
+    if (send) { np = 0; last = 0; }
     tmax = np;
     for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+
+    // rows of this wave: [row_lo, row_hi)
+    int row_lo = 0, row_hi = tmax;
+    if (!whole) {
+        const int seg_len = (tmax + a.split - 1) / a.split;
+        row_lo = seg * seg_len;
+        row_hi = min(tmax, row_lo + seg_len);
+        if (row_lo >= row_hi) return;
+    }
 
     // backward walk
     unsigned long long seen[MW];
 #pragma unroll
     for (int w = 0; w < MW; ++w) seen[w] = 0ull;
     int cur_ix = -1;
-    for (int s0 = tmax - 1; s0 >= 0; s0 -= HM_UNROLL) {
+    if (row_hi < tmax) {
+        // The walk starts inside the ray: the rows already seen in the column of its first row are the ones the ray
+        // visits right AFTER that row while it stays in the column (columns never decrease), so they are collected by
+        // walking forward from row_hi until every lane has left its column.
+        bool more = np > row_hi;                             // this lane has rows above the range
+        int ix_top = -1;
+        {
+            const int64_t o = base + (int64_t)min(max(row_hi - 1, 0), last) * RT2D_WAVE;
+            int iz;
+            rt2d_cell_i32(a.geo, a.X[o], a.Z[o], ix_top, iz);
+        }
+        if (more) cur_ix = ix_top;
+        for (int s = row_hi; __any(more && s < np); ++s) {
+            const int64_t o = base + (int64_t)min(s, last) * RT2D_WAVE;
+            int ix, iz;
+            rt2d_cell_i32(a.geo, a.X[o], a.Z[o], ix, iz);
+            more = more && s < np && ix == ix_top;
+            if (more) {
+#pragma unroll
+                for (int w = 0; w < MW; ++w) if (w == (iz >> 6)) seen[w] |= 1ull << (iz & 63);
+            }
+        }
+    }
+    for (int s0 = row_hi - 1; s0 >= row_lo; s0 -= HM_UNROLL) {
         double xs[HM_UNROLL], zs[HM_UNROLL], gs[HM_UNROLL];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
@@ -1453,7 +1499,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             int cell = -1 - lane;                           // unique per lane: never merges
             double val = 0.0;
             late_cell[u] = 0;
-            if (s >= 0 && s < np) {
+            if (s >= row_lo && s < np) {
                 int ix, iz;
                 rt2d_cell_i32(a.geo, xs[u], zs[u], ix, iz);
                 if (ix != cur_ix) {
@@ -2163,8 +2209,13 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
         a.work = work;
         HIP_OK(hipMemsetAsync(work, 0, 2 * sizeof(int32_t), stream));
         const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
-        const int wpb = (n_tiles <= 1024) ? 1 : 4;
-        const unsigned blocks = (unsigned)((n_tiles + wpb - 1) / wpb);
+        static const int max_split = getenv("RT2D_HM_SPLIT") ? atoi(getenv("RT2D_HM_SPLIT")) : 16;
+        int split = 1;
+        while (split < max_split && n_tiles * split < 4096) split *= 2;    // enough waves to give every SIMD several
+        a.split = split;
+        const int64_t n_waves = n_tiles * split;
+        const int wpb = (n_waves <= 1024) ? 1 : 4;
+        const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
         if (shape[1] <= 64) hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<1>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
         else hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<4>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
         HIP_OK(hipGetLastError());
