@@ -124,10 +124,12 @@ __device__ __forceinline__ double rt2d_heat_val_pows(double g) {
     double tmult = pow(10.0, g / 10);
     return pow(tmult, -0.1);
 }
-// An infinite gain needs no pow either: 10^(-inf/10) = 0 and 0^-0.1 = inf; 10^(inf/10) = inf and inf^-0.1 = 0.  It is the
-// common case at high frequency, where the surface coefficient exp(-2 (k h sin a)^2) underflows to 0 at the first
-// surface rebound and every later point of the ray carries G = -inf (ray.py:350-362).
-__device__ __forceinline__ bool rt2d_heat_val_is_inf(double g) { return fabs(g) == INFINITY; }
+// Far outside that range no pow is needed either: 10^(G/10) has overflowed to inf for G > 3090 (value inf^-0.1 = 0) and
+// underflowed to 0 -- below half the smallest denormal, 10^-323.6 -- for G < -3240 (value 0^-0.1 = inf), infinities
+// included.  This is the common case at high frequency: the surface coefficient exp(-2 (k h sin a)^2) is 1e-300 or 0
+// from the first surface rebound on, and every later point of the ray carries G of minus thousands of dB or -inf
+// (ray.py:350-362).  Only the bands in between take the two pows.
+__device__ __forceinline__ bool rt2d_heat_val_is_inf(double g) { return g < -3240.0 || g > 3090.0; }
 __device__ __forceinline__ double rt2d_heat_val_of_inf(double g) { return (g < 0.0) ? INFINITY : 0.0; }
 __device__ __forceinline__ double rt2d_heat_val(double g) {
     if (rt2d_heat_val_is_plain(g)) return rt2d_heat_val_plain(g);
