@@ -271,7 +271,8 @@ int32_t rt2d_target_products(rt2d_env_t env, const double* X, const double* Z, c
  * ray_mask: device, n bytes, nonzero = bin this ray (NULL = all n rays; a RayPack may hold a subset of a fan).
  *   Bit 2 (value 2) is a HINT the caller may add: "x never decreases along this ray (Rt2dRayOut.monotone) and every
  *   point of it falls inside the map"; the tile kernel then skips its own check of exactly that.  A wrong hint gives
- *   a wrong map.
+ *   a wrong map.  Bit 4 (value 4) says the opposite, "known not to qualify": where the tile kernel shares a tile among
+ *   several waves (fans of 10^4..10^5 rays) such a ray goes to the general kernel without being checked.
  * G: device, one frequency, tile layout.  res: host, 2 ints (metres per cell in x and z).
  * shape: host, 2 ints (nx, nz).  H: device, nx*nz doubles row-major [ix*nz + iz], accumulated into
  * (caller zeroes it).  n_dropped (device int64, may be NULL, caller zeroes it) counts points whose flat index

@@ -1402,9 +1402,10 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     bool ok = true;
     int prev_ix = INT32_MIN;
     // A shared tile cannot run the point-by-point check (its verdict would have to cross waves): if some of its rays are
-    // vouched for, the others go straight to the general kernel, which takes any ray; a tile without a single vouched-for
-    // ray (the caller gave no hints) is checked and walked whole by its first wave.
-    const bool send = a.split > 1 && __any(hinted) && mine && !hinted;
+    // vouched for, or the caller marked the others as known not to qualify (bit 4 of ray_mask), the others go straight
+    // to the general kernel, which takes any ray; a tile without either (the caller gave no hints) is checked and walked
+    // whole by its first wave -- the slowest wave of the launch when the fan has few tiles.
+    const bool send = a.split > 1 && mine && !hinted && (__any(hinted) || (flags & 4) != 0);     // bit 4: known not to qualify
     const bool all_hinted = __all(hinted || !mine || send);
     if (!all_hinted && seg > 0) return;
     const bool whole = a.split == 1 || !all_hinted;

@@ -442,7 +442,8 @@ class RayFan:
                   & (torch.div(torch.trunc(rng[2]), int(res[0]), rounding_mode='floor') < int(shape[0]))
                   & (torch.div(-torch.trunc(rng[1]), int(res[1]), rounding_mode='floor') < int(shape[1])))
         base = torch.ones(self.n, dtype=torch.uint8, device=self.device) if ray_mask is None else (ray_mask != 0).to(torch.uint8)
-        return base + 2 * (base * (inside & (self.monotone != 0)).to(torch.uint8))
+        good = base * (inside & (self.monotone != 0)).to(torch.uint8)
+        return base + 2 * good + 4 * (base - good)          # 1 | 2: vouched for; 1 | 4: known not to qualify
 
     def fused_mask(self, res, shape, ray_mask=None):
         """uint8 mask of the rays rt2d_cast_heatmap may bin (include/rt2d.h): no error, x never decreases, bounding box
