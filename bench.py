@@ -214,7 +214,7 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     else:
         # ray_mask with the hint bit: x never decreases (from the cast) and the ray's bounding box is inside the map
         mask = okm.to(torch.uint8)
-        if n > 16384:          # the tile kernel's range (rt2d_heatmap_accumulate); smaller fans use the general kernel
+        if n > 6000:           # the tile kernel's range (rt2d_heatmap_accumulate); smaller fans use the general kernel
             inside = ((rng[0] > -1) & (rng[3] < 1) & (torch.div(torch.trunc(rng[2]), RES[0], rounding_mode='floor') < int(shape[0]))
                       & (torch.div(-torch.trunc(rng[1]), RES[1], rounding_mode='floor') < int(shape[1])))
             mask = mask * (1 + 2 * (inside & (mono != 0)).to(torch.uint8))

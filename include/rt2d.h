@@ -278,7 +278,7 @@ int32_t rt2d_target_products(rt2d_env_t env, const double* X, const double* Z, c
  * (caller zeroes it).  n_dropped (device int64, may be NULL, caller zeroes it) counts points whose flat index
  * falls outside [-nx*nz, nx*nz) -- the reference raises IndexError there.
  * work: device workspace of n + 2 int32 (contents irrelevant on entry), or NULL.  With a workspace, nz <= 256 and
- * more than 16384 rays (env RT2D_HEATMAP_FAST_MIN_RAYS overrides), rays that only move forward in x and stay inside
+ * more than 6000 rays (env RT2D_HEATMAP_FAST_MIN_RAYS overrides), rays that only move forward in x and stay inside
  * the map are binned by a coalesced one-wave-per-tile kernel and only the remaining rays go through the general
  * one-wave-per-ray hash kernel; otherwise every ray does.  On return work[0] = number of rays the general kernel
  * handled after the tile kernel, or -1 if the tile kernel was not used. */

@@ -2201,8 +2201,8 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     static const int hm_cells = getenv("RT2D_HM_CELLS") ? atoi(getenv("RT2D_HM_CELLS")) : 4096;
     a.cap = hm_cap; a.cell_cap = hm_cells;
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
-    // below ~16k rays the latter finishes first
-    static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 16384;
+    // below ~6000 rays the latter finishes first (measured with the rows of a tile shared by up to 16 waves)
+    static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 6000;
     // (the tile kernel works on 32-bit cells: every point inside the map must have |x|, |z| < 2^31)
     const bool small_coords = res[0] < (1 << 20) && res[1] < (1 << 20) &&
                               (int64_t)shape[0] * res[0] < (1ll << 31) && (int64_t)shape[1] * res[1] < (1ll << 31);

@@ -22,7 +22,7 @@ from . import _lib
 from ._lib import STOP_REASONS, RAY_ERR_INTERP
 
 TILE = 64
-HEATMAP_FAST_MIN_RAYS = int(os.environ.get('RT2D_HEATMAP_FAST_MIN_RAYS', 16384))    # same switch as the library's
+HEATMAP_FAST_MIN_RAYS = int(os.environ.get('RT2D_HEATMAP_FAST_MIN_RAYS', 6000))    # same switch as the library's
 SPECULATIVE_ROOM = 4096          # points per ray a speculative single-pass cast reserves
 SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below this
 # Big fans: 288 GB of HBM make the counting pass optional.  The same single storing pass goes into a PADDED layout

@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-# exercise the coalesced heat-map tile kernel on the small test fans too (default threshold: 16384 rays)
+# exercise the coalesced heat-map tile kernel on the small test fans too (default threshold: 6000 rays)
 os.environ.setdefault('RT2D_HEATMAP_FAST_MIN_RAYS', '0')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
