@@ -65,3 +65,24 @@ def test_million_ray_fan_properties(rt):
     lean.heatmap_accumulate(H_f, res, shape, freq=1)
     assert int(lean.last_fused_violations.item()) == 0
     assert float((H_f - H_all).abs().max().item()) <= tol
+
+
+def test_mid_size_fan_tile_binner_equals_general_binner(rt):
+    """20 000 rays: few tiles, so the tile binner shares each tile's rows among several waves and hands the rays marked
+    "known not to qualify" (ray_mask bit 4) to the general kernel unchecked; the general kernel alone must give the same
+    map, with and without the caller's hints."""
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    n = 20000
+    angles = -(np.arange(n) + 1) * (0.999 / n)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    fan = sim.cast(angles, **common.prop_kwargs(g))
+    for freq in (1., 12000.):
+        Hg, _ = sim.heatmap_full(resolution=[50, 25], freq=freq, fast=False)
+        for hint in (True, False):
+            Ht, _ = sim.heatmap_full(resolution=[50, 25], freq=freq, fast=True, hint=hint)
+            assert 0 < fan.last_slow_rays < n // 5
+            Ht_, Hg_ = Ht.cpu().numpy(), Hg.cpu().numpy()
+            assert np.array_equal(np.isfinite(Ht_), np.isfinite(Hg_)) and np.array_equal(Ht_ == 0, Hg_ == 0)
+            fin = np.isfinite(Hg_)
+            assert np.abs(Ht_[fin] - Hg_[fin]).max() <= 1e-12 * np.abs(Hg_[fin]).max()
