@@ -2078,7 +2078,10 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     const int fch = n_freqs >= 8 ? 8 : (n_freqs >= 3 ? 4 : n_freqs);      // frequencies per lane: amortises the 6 table evals
     const char* tp = getenv("RT2D_GAIN_TWO_PHASE_MAX_RAYS");              // tests force either path with this
     const size_t scan_lds = (size_t)GAIN_SCAN_ROWS * RT2D_WAVE * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * RT2D_WAVE * 12;
-    if (G && n <= (tp ? atoll(tp) : 64 * 512) && scan_lds <= RT2D_LDS_BUDGET) {
+    // (measured crossovers: one frequency 65536 rays 1.40 -> 1.06 ms, 131072 rays 1.59 -> 1.96 ms; 65536 rays x 8
+    // frequencies 4.8 -> 3.7 ms, x 64 frequencies slower again: the scan launches a workgroup per (tile, frequency))
+    const bool two_phase = tp ? n <= atoll(tp) : (n <= 64 * 512 || (n <= 90000 && n * (int64_t)n_freqs <= 600000));
+    if (G && two_phase && scan_lds <= RT2D_LDS_BUDGET) {
         // small fan: per-point dG on the whole chip, then the running sums (see rt2d_gain_dg_kernel)
         const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
         const unsigned split = (unsigned)(n_tiles >= 512 ? 4 : (2048 + n_tiles - 1) / n_tiles);
