@@ -351,24 +351,44 @@ def main():
     ap.add_argument('--large-rays', type=int, default=1 << 20, help='rays of the large-fan block (0 = skip)')
     ap.add_argument('--large-steps', type=int, default=3)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='run the two all-reduces of the step even in a group of one rank (rehearses RCCL on a 1-GPU box)')
+    ap.add_argument('--dry-run', action='store_true', help='ranks print their torch.distributed environment and exit (launcher test)')
     args = ap.parse_args()
+
+    if args.dry_run and 'WORLD_SIZE' in os.environ:
+        print(json.dumps({'rank': int(os.environ['RANK']), 'local_rank': int(os.environ['LOCAL_RANK']),
+                          'world': int(os.environ['WORLD_SIZE']), 'port': os.environ['MASTER_PORT']}), flush=True)
+        sys.exit(int(os.environ.get('RT2D_BENCH_DRY_FAIL_RANK', '-1')) == int(os.environ['RANK']))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks and never touches the GPU
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    dev_index = local_rank % torch.cuda.device_count()      # one rank per GPU; wraps only when rehearsed on fewer GPUs
+    if world != args.gpus and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher decides, running {world} ranks', file=sys.stderr)
+    n_dev = torch.cuda.device_count()                       # (does not initialise the GPU)
+    assert n_dev > 0, 'bench.py needs a GPU'
+    dev_index = local_rank % n_dev                          # one rank per GPU; wraps only when rehearsed on fewer GPUs
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    if world > 1:
+    backend = None
+    if world > 1 or args.force_collectives:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('RT2D_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; gloo only to rehearse on one GPU
+        os.environ.setdefault('MASTER_PORT', '29533')
+        # "nccl" is RCCL on ROCm.  RCCL wants one GPU per rank: with more ranks than GPUs (a rehearsal on a 1-GPU box) the
+        # collectives go over gloo instead, and the JSON line says so
+        backend = os.environ.get('RT2D_DIST_BACKEND', 'nccl' if world <= n_dev else 'gloo')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+    collectives = world > 1 or args.force_collectives
 
     import rt2d_loader
     rt = rt2d_loader.load()
@@ -386,12 +406,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(rt, torch, env, source, angles_dev, collectives=world > 1, device=device)
+        one_step(rt, torch, env, source, angles_dev, collectives=collectives, device=device)
     stages = Stages(torch)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, n_pts, status, hm = one_step(rt, torch, env, source, angles_dev, stages=stages, collectives=world > 1, device=device)
+        _, n_pts, status, hm = one_step(rt, torch, env, source, angles_dev, stages=stages, collectives=collectives, device=device)
     barrier()
     dt = time.perf_counter() - t0
     steps_rank = ray_steps_of(n_pts, status)
@@ -414,7 +434,8 @@ def main():
         traffic, traffic_src = pmc_traffic(large=False)
         result = {
             'metric': 'ray-steps/sec (node) + s per 999-ray 20-rebound heatmap', 'value': value, 'unit': 'ray-steps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'n_gpus': world, 'ranks': dist.get_world_size() if backend else 1,
+            'collective_backend': None if not backend else ('nccl (RCCL)' if backend == 'nccl' else backend), 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'c2_fan999: 999 rays/GPU (-(j+1)/(1000 N) rad), 20 rebounds, dx_max 50, dz_max 25, '
                                    'floor max(-e^{0.0005x}-500,-1500+0.02x) over 75 km, gain @1 Hz, heat map 50x25 m, cutoff 0.5, reduction power 0.5',
@@ -551,8 +572,40 @@ def main():
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline()
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if backend:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this script, one rank per GPU, with
+    the torch.distributed environment set (what `python -m torch.distributed.run --nproc-per-node N` would do), BEFORE
+    anything in this process has touched the GPU.  Rank 0 prints the JSON line on the inherited stdout.  Returns the
+    exit status: non-zero as soon as any rank fails (the others are then ended by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:          # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
 
 
 if __name__ == '__main__':

@@ -226,10 +226,10 @@ def c3():
     zmin = float(np.floor(z.min())) - 1.
     spec = env_spec(fl, ce, [0., zmin], [60000., 1.])
     spec['cut_length_m'] = np.float64(d)
-    angles = np.array([i / 1000 for i in range(-1, -1000, -4)])
+    angles = np.array([i / 1000 for i in range(-1, -1000, -1)])          # all 999 angles of config 3
     prop = dict(dx_max=50., dz_max=25., n_rebounds_max=20)
     out, _ = run_fan(make_env(spec), [0., 0.], angles, [1], **prop)
-    save('c3_bathy250', spec, fan_dict([0., 0.], angles, [1], **prop), out)
+    save('c3_bathy999', spec, fan_dict([0., 0.], angles, [1], **prop), out)
 
 
 def c4():

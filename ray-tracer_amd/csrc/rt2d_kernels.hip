@@ -19,7 +19,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt2d.h"
@@ -209,8 +212,11 @@ struct RayBinner {
             if (stay) { slot[k * RT2D_WAVE] = v; occ |= 1u << k; }
         }
         const int cell = cur_ix * t.nz + cur_iz;
-        if (t.dbg & 1) { if (want) atomicAdd(&t.H[cell], v - prev); }
-        else rt2d_deposit(t.H, want, cell, v - prev, lane);
+        // never the difference of two infinities: a gain of -inf (a surface coefficient that underflowed, ray.py:350-362)
+        // gives v = prev = +inf on a row the ray comes back to, and the cell already holds the +inf the reference puts there
+        const double d = (v == prev) ? 0.0 : v - prev;
+        if (t.dbg & 1) { if (want) atomicAdd(&t.H[cell], d); }
+        else rt2d_deposit(t.H, want, cell, d, lane);
     }
     // first point of the ray (gain g)
     __device__ __forceinline__ void start(const BinTarget& t, bool enabled, double* slot_, double x, double z, double g) {
@@ -1664,16 +1670,27 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
 }
 
 // presentation (simulation.py:133-138)
+// np.max over the map: doubles of either sign are ordered through a key whose unsigned order is the numbers' order
+// (sign bit flipped for values >= 0, all bits flipped for negative ones), so one 64-bit atomicMax per wave does it and a
+// map accumulated with a negative sign (rt2d_cast_heatmap's `sign`) normalises by its true maximum.
+__device__ __forceinline__ unsigned long long rt2d_order_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double rt2d_order_value(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
 __global__ void rt2d_hm_max_kernel(const double* H, int64_t size, unsigned long long* scratch) {
-    // scratch[0]: bit pattern of max over non-negative values; scratch[1]: NaN flag
-    double m = 0.0; bool nan = false;
+    // scratch[0]: order key of the maximum (0 = nothing seen yet); scratch[1]: NaN flag
+    double m = -INFINITY; bool nan = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += (int64_t)gridDim.x * blockDim.x) {
         double v = H[i];
         if (v != v) nan = true; else m = fmax(m, v);
     }
     for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); nan = nan || __shfl_xor((int)nan, off); }
     if ((threadIdx.x & 63) == 0) {
-        atomicMax(&scratch[0], (unsigned long long)__double_as_longlong(m));
+        atomicMax(&scratch[0], rt2d_order_key(m));
         if (nan) atomicMax(&scratch[1], 1ull);
     }
 }
@@ -1682,7 +1699,7 @@ __global__ void rt2d_hm_finalize_kernel(const double* H, int64_t nx, int64_t nz,
                                         const unsigned long long* scratch, double* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nx * nz) return;
-    double mx = scratch[1] ? __builtin_nan("") : __longlong_as_double((long long)scratch[0]);
+    double mx = scratch[1] ? __builtin_nan("") : rt2d_order_value(scratch[0]);
     int64_t ix = i / nz, iz = i % nz;
     double v = H[i] / mx;
     if (v > cutoff) v = cutoff;
@@ -1807,6 +1824,24 @@ int32_t rt2d_env_surface_speed(rt2d_env_t env, double* c0_out) {
 
 #define RT2D_LDS_BUDGET (152 * 1024)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size growth) instead of once per launch: a
+// 999-ray step is ten launches inside 1.3 ms, and the attribute call costs a few microseconds of host time each.
+extern "C++" {
+static int32_t rt2d_allow_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[std::make_pair(dev, kernel)];
+    if (bytes <= have) return 0;
+    HIP_OK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return 0;
+}
+}
+#define ALLOW_LDS(kernel, bytes) do { int32_t rc_ = rt2d_allow_lds((const void*)(kernel), (size_t)(bytes)); if (rc_) return rc_; } while (0)
+
 extern "C++" {
 static int post_level(const Rt2dRayOut& o) {
     if (o.L_end || o.T_end || o.dist_to_target || o.step_target || o.T_target || o.margin) return 2;
@@ -1848,7 +1883,7 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     if (in_lds) {
         auto k = env->ceil_is_const ? rt2d_cast_kernel<WRITE, true, POST, CUTOFF, true> : rt2d_cast_kernel<WRITE, true, POST, CUTOFF, false>;
         a.ceil_const = env->ceil_const;
-        HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ALLOW_LDS(k, lds);
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
     } else {
         hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST, CUTOFF, false>), dim3((unsigned)grid), dim3(block), lds, stream, a);
@@ -1968,7 +2003,7 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     a.fuse_loss = loss; a.fuse_loss_cap = loss ? loss_cap : 0;
     auto k = loss ? (env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, 2> : rt2d_cast_kernel<false, true, 1, false, false, 2>)
                   : (env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, 1> : rt2d_cast_kernel<false, true, 1, false, false, 1>);
-    HIP_OK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALLOW_LDS(k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
@@ -2034,7 +2069,7 @@ int32_t rt2d_post(rt2d_env_t env, const double* X, const double* Z, const int64_
     a.dL = dL; a.L = L; a.C = C; a.dT = dT; a.T = T;
     const size_t lds = (size_t)env->dev.cz_doubles * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_post: sound-speed table does not fit in LDS");
-    HIP_OK(hipFuncSetAttribute((const void*)rt2d_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALLOW_LDS(rt2d_post_kernel, lds);
     const int block = (n <= 64 * 512) ? 64 : 256;
     hipLaunchKernelGGL(rt2d_post_kernel, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
@@ -2088,9 +2123,9 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
         dim3 grid1((unsigned)n_tiles, split, (unsigned)((n_freqs + fch - 1) / fch));
         void (*k1)(const GainArgs) = fch == 8 ? rt2d_gain_dg_kernel<8> : fch == 4 ? rt2d_gain_dg_kernel<4>
                                     : fch == 2 ? rt2d_gain_dg_kernel<2> : rt2d_gain_dg_kernel<1>;
-        HIP_OK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ALLOW_LDS(k1, lds);
         hipLaunchKernelGGL(k1, grid1, dim3(256), lds, (hipStream_t)stream, a);
-        HIP_OK(hipFuncSetAttribute((const void*)rt2d_gain_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds));
+        ALLOW_LDS(rt2d_gain_scan_kernel, scan_lds);
         hipLaunchKernelGGL(rt2d_gain_scan_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs), dim3(GAIN_SCAN_THREADS), scan_lds, (hipStream_t)stream, a);
         HIP_OK(hipGetLastError());
         return 0;
@@ -2110,7 +2145,7 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
         kern = fch == 8 ? rt2d_gain_kernel<8, false> : fch == 4 ? rt2d_gain_kernel<4, false>
              : fch == 2 ? rt2d_gain_kernel<2, false> : rt2d_gain_kernel<1, false>;
     }
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
@@ -2147,7 +2182,7 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
         a.loss = loss_ws;
         kern = rt2d_gain_heatmap_kernel<true>;
     }
-    HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
     HIP_OK(hipGetLastError());
     return 0;
@@ -2182,11 +2217,25 @@ int32_t rt2d_target_products(rt2d_env_t env, const double* X, const double* Z, c
     return 0;
 }
 
+extern "C++" {
+static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                       const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                       const int32_t* res, const int32_t* shape,
+                                       double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream);
+}
+
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                 const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                 const int32_t* res, const int32_t* shape,
                                 double* H, int64_t* n_dropped, int32_t* work, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return heatmap_accumulate_impl(X, Z, G, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream_);
+}
+
+extern "C++" {
+static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                       const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                       const int32_t* res, const int32_t* shape,
+                                       double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream) {
     if (!X || !Z || !G || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
     if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
     if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
@@ -2232,6 +2281,7 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     HIP_OK(hipGetLastError());
     return 0;
 }
+}  // extern "C++"
 
 int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, double reduction_power,
                               double* out, double* scratch, void* stream_) {

@@ -9,7 +9,7 @@ GPU, so every field is converted ONCE, on the host, into a :class:`PPTable`:
     value(x) = (c0*d + c1)*d + c2     with d = x - breaks[j]      (order 3, quadratic)
     value(x) =  c0*d + c1             with d = x - breaks[j]      (order 2, linear)
 
-evaluated without FMA contraction.  The HIP kernels (csrc/rt2d_tables.h) evaluate exactly this
+evaluated without FMA contraction.  The HIP kernels (csrc/rt2d_device.h) evaluate exactly this
 expression, so host ``PPTable.__call__`` and device lookups agree bit for bit.
 
 ``quadratic_interp_table`` builds the same spline as ``interp1d(kind='quadratic')``

@@ -397,7 +397,9 @@ class RayFan:
         """Cumulative gain [dB] for every ray at the given frequencies (new ones only)."""
         self._need_store()
         torch = _torch()
-        new = [f for f in dict.fromkeys(freqs) if f not in self.G_end]
+        # a frequency whose end gains are known but whose array was not kept (keep_arrays=False) is new again when the
+        # arrays are asked for
+        new = [f for f in dict.fromkeys(freqs) if f not in self.G_end or (keep_arrays and f not in self.G)]
         if not new:
             return
         if self.padded and keep_arrays and len(new) + len(self.G) > 1:

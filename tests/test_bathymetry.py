@@ -80,11 +80,11 @@ def test_from_asc_rejects_a_truncated_header(rt, tmp_path):
 
 @pytest.mark.gpu
 def test_fan_over_a_map_cut_on_the_gpu(rt, cut):
-    """Config 3 end to end: .asc -> Map.cut -> floor table -> fan.  The golden fan c3_bathy250 was cast by the reference
+    """Config 3 end to end: .asc -> Map.cut -> floor table -> fan.  The golden fan c3_bathy999 was cast by the reference
     over this same cut stretched to 60 km; the environment built straight from the Map must reproduce the fan cast on
     the fixture's stored floor bit for bit, and hence the reference's terminations and rebound counts."""
     import torch
-    g = common.load('c3_bathy250')
+    g = common.load('c3_bathy999')
     m = rt.Map.from_asc(ASC)
     _, z = m.cut(tuple(cut['start']), tuple(cut['stop']), npoints=int(cut['npoints']))
     floor = rt.linear_interp_table(np.linspace(0., 60000., len(z)), z, oob=1)

@@ -45,3 +45,30 @@ def test_two_ranks_equal_one_process(rt, tmp_path):
         assert np.array_equal(got[r]['scan_selected'], g['scan_selected_angles'])
         assert abs(float(got[r]['final_dist_avg']) - float(g['final_dist_avg'])) < 1e-6
     assert np.array_equal(got[0]['final_angles'], got[1]['final_angles'])
+
+
+def test_bench_gpus_2_from_a_plain_invocation():
+    """`python bench.py --gpus 2` with no launcher around it prints ONE JSON line with n_gpus 2 (two ranks on the one
+    card here, so the collectives go over gloo and the line says so; with a GPU per rank they go over RCCL)."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--large-rays', '0', '--no-cpu'], capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['ranks'] == 2 and rec['scaling'] == 'weak'
+    assert rec['collective_backend'] in ('gloo', 'nccl (RCCL)')
+    assert rec['config']['rays_per_gpu'] == 999 and rec['value'] > 0
+
+
+def test_collectives_over_rccl_in_a_group_of_one():
+    """The two all-reduces of the step through the nccl backend (= RCCL on ROCm) on this box's one GPU: a group of one
+    rank, so the RCCL path has run before an 8-GPU node sees it.  Same line otherwise as the plain N = 1 run."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--force-collectives', '--steps', '3', '--warmup', '1',
+                          '--large-rays', '0', '--no-cpu'], capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['n_gpus'] == 1 and rec['ranks'] == 1 and rec['collective_backend'] == 'nccl (RCCL)'
+    assert rec['config']['heatmap_shape'][0] > 40 and rec['value'] > 0

@@ -24,7 +24,7 @@ def _maps(rt, g, angles=None, freq=1, res=(50, 25), env=None, **over):
     return Hs.cpu().numpy(), Hf.cpu().numpy(), fan, stored, fused
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
 def test_fused_map_equals_stored_map(rt, name):
     g = common.load(name)
     Hs, Hf, fan, stored, fused = _maps(rt, g)
@@ -51,7 +51,10 @@ def test_fused_other_frequencies_and_cells(rt, freq, res):
     print(f'freq {freq} res {res}: {fan.last_slow_rays} of {fan.n} rays through the general path')
     assert np.array_equal(Hf == 0, Hs == 0)
     both = np.isfinite(Hs) & (Hs != 0)
-    assert np.array_equal(np.isfinite(Hf), np.isfinite(Hs))
+    # a surface rebound at high frequency gives G = -inf, i.e. a deposited value of +inf: the same cells must hold it in
+    # both maps, and no cell may turn into NaN (inf - inf when a ray comes back to a row it left inside one column)
+    assert np.array_equal(np.isinf(Hf), np.isinf(Hs))
+    assert not np.isnan(Hf).any() and not np.isnan(Hs).any()
     assert (np.abs(Hf - Hs)[both] / np.abs(Hs[both])).max() < 1e-12
 
 

@@ -32,7 +32,7 @@ def _oracle_post(orc, oenv, r, target=None):
 
 def test_post_arrays_bit_exact(rt, orc):
     """dL, L, C, dT, T of rt2d_post equal the oracle's bit for bit on the same points (ray.py:271-275)."""
-    g = common.load('c3_bathy250')
+    g = common.load('c3_bathy999')
     fan, env = _cast(rt, g)
     oenv = common.oracle_env_from_product(orc, env)
     rays = _oracle_rays_from_fan(orc, rt, fan)
@@ -119,7 +119,7 @@ def test_gain_vs_oracle_same_points(rt, orc):
 
 
 @pytest.mark.parametrize('fast', [True, 'nohint', False])
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
 def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
     """Binning in isolation: oracle heat map over the GPU's own points and gains -> every cell equal to 1e-12.
     fast=True: coalesced tile kernel + general kernel for the queued rays; fast=False: general kernel only."""
@@ -149,7 +149,7 @@ def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
         assert np.abs(out - plot_ref).max() < 1e-12
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
 def test_heatmap_vs_reference(rt, name):
     """Whole pipeline against the reference's heat map; bin-edge disagreements are counted and bounded."""
     g = common.load(name)
@@ -189,6 +189,14 @@ def test_heatmap_vs_reference(rt, name):
     assert n_bad <= 0.02 * H.size
     # the mass of the map moves by at most ~one deposit per edge point (a flip can merge two cells of one ray)
     assert abs(H.sum() - ref.sum()) <= 1e-9 * ref.sum() + 2.0 * int(edge.sum())
+    # the presented maps at the three saturation levels of the sample images (simulation.py:133-138): the normalising
+    # maximum agrees, and so does every cell outside the ones counted above
+    assert abs(H.max() - ref.max()) <= 1e-9 * ref.max()
+    for cutoff in (.02, .1, .5):
+        out = sim.heatmap(resolution=res, cutoff=cutoff, reduction_power=.5)
+        want = g[f'heatmap_plot_cut{cutoff}']
+        assert out.shape == want.shape
+        assert np.abs(out - want)[~differ.T].max() < 1e-9
 
 
 def test_heatmap_backward_and_out_of_map_rays(rt, orc):
@@ -326,3 +334,39 @@ def test_extreme_gains_take_the_pow_path_in_both_kernels(rt):
     assert np.array_equal(np.isinf(got), np.isinf(want))
     f = np.isfinite(want)
     assert np.abs(got[f] - want[f]).max() <= 1e-12 * max(1.0, np.abs(want[f]).max())
+
+
+def test_finalize_of_a_negative_map(rt):
+    """rt2d_heatmap_finalize normalises by np.max of the map whatever its sign (rt2d_cast_heatmap can accumulate with
+    sign = -1): a map of negative cells against the NumPy expression of simulation.py:133-136, and a NaN cell -> NaN."""
+    import torch
+    rng = np.random.default_rng(3)
+    nx, nz = 37, 11
+    for H in (-(rng.random((nx, nz)) * 5 + 1), rng.random((nx, nz)) * 3, rng.normal(size=(nx, nz)) + 0.1):
+        Hd = torch.from_numpy(np.ascontiguousarray(H)).cuda()
+        out = torch.empty((nz, nx), dtype=torch.float64, device='cuda')
+        scratch = torch.empty(2, dtype=torch.float64, device='cuda')
+        rt._lib.check(rt._lib.lib().rt2d_heatmap_finalize(Hd.data_ptr(), (C.c_int32 * 2)(nx, nz), .5, 1.0, out.data_ptr(),
+                                                          scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        norm = H / np.max(H)
+        norm[norm > .5] = .5
+        assert np.abs(out.cpu().numpy() - norm.T).max() < 1e-15
+    Hn = torch.ones((nx, nz), dtype=torch.float64, device='cuda')
+    Hn[3, 4] = float('nan')
+    out = torch.empty((nz, nx), dtype=torch.float64, device='cuda')
+    scratch = torch.empty(2, dtype=torch.float64, device='cuda')
+    rt._lib.check(rt._lib.lib().rt2d_heatmap_finalize(Hn.data_ptr(), (C.c_int32 * 2)(nx, nz), .5, .5, out.data_ptr(),
+                                                      scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert bool(torch.isnan(out).all().item())            # np.max of a map with a NaN is NaN, and so is every quotient
+
+
+def test_populate_after_keep_arrays_false(rt):
+    """A frequency populated with keep_arrays=False (end gains only) gets its array when it is asked for later."""
+    g = common.load('c1_flat250')
+    fan, env = _cast(rt, g, angles=g['fan_angles'][:70])
+    fan.populate(1000., keep_arrays=False)
+    assert 1000. in fan.G_end and 1000. not in fan.G
+    import torch
+    H = torch.zeros(1100 * 45, dtype=torch.float64, device='cuda')
+    fan.heatmap_accumulate(H, (50, 25), (1100, 45), freq=1000.)
+    assert 1000. in fan.G and float(H.sum().item()) > 0

@@ -21,7 +21,7 @@ def _both(rt, g, angles=None, freq=1, res=(50, 25)):
     return Hs, Hr.cpu().numpy(), fan, slow, viol
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
 def test_stream_map_equals_two_pass_map(rt, name):
     Hs, Hr, fan, slow, viol = _both(rt, common.load(name))
     assert viol == 0 and slow < fan.n // 2
@@ -34,7 +34,8 @@ def test_stream_other_frequencies_and_cells(rt, freq, res):
     g = common.load('c2_fan999')
     Hs, Hr, fan, slow, viol = _both(rt, g, angles=g['fan_angles'][::3], freq=freq, res=res)
     assert viol == 0
-    assert np.array_equal(Hs == 0, Hr == 0) and np.array_equal(np.isfinite(Hs), np.isfinite(Hr))
+    assert np.array_equal(Hs == 0, Hr == 0) and np.array_equal(np.isinf(Hs), np.isinf(Hr))
+    assert not np.isnan(Hs).any() and not np.isnan(Hr).any()
     both = np.isfinite(Hr) & (Hr != 0)
     assert (np.abs(Hs - Hr)[both] / np.abs(Hr[both])).max() < 1e-12
 

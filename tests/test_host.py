@@ -3,6 +3,7 @@
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -193,3 +194,19 @@ def test_ctypes_signatures_follow_the_header(rt):
         assert at is not None and len(at) == n, (name, n, at)
         seen += 1
     assert seen == len(rt._lib.EXPORTS)
+
+
+def test_bench_launches_one_process_per_gpu():
+    """`python bench.py --gpus N` (no launcher around it) starts N ranks itself, with the torch.distributed environment
+    set, before anything touches a GPU; a failing rank makes the whole run fail.  --dry-run: the ranks only print."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, 'bench.py')
+    out = subprocess.run([sys.executable, bench, '--gpus', '4', '--dry-run'], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = sorted((json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')), key=lambda r: r['rank'])
+    assert [r['rank'] for r in recs] == [0, 1, 2, 3] and all(r['world'] == 4 and r['local_rank'] == r['rank'] for r in recs)
+    assert len({r['port'] for r in recs}) == 1
+    env = dict(os.environ, RT2D_BENCH_DRY_FAIL_RANK='2')
+    bad = subprocess.run([sys.executable, bench, '--gpus', '4', '--dry-run'], capture_output=True, text=True, timeout=60, env=env)
+    assert bad.returncode != 0

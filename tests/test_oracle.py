@@ -12,14 +12,14 @@ from common import TRAJ_RTOL, TRAJ_RTOL_WORST, KNIFE_EDGE_M
 @pytest.fixture(scope='module')
 def fans(orc):
     out = {}
-    for name in ('c1_flat250', 'c2_fan999', 'c3_bathy250', 'c4_multifreq', 't2_single'):
+    for name in ('c1_flat250', 'c2_fan999', 'c3_bathy999', 'c4_multifreq', 't2_single'):
         g = common.load(name)
         env = common.oracle_env(orc, g)
         out[name] = (g, env, common.oracle_fan(orc, env, g))
     return out
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250', 'c4_multifreq', 't2_single'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999', 'c4_multifreq', 't2_single'])
 def test_discrete_outcomes_and_trajectories(fans, name):
     g, env, rays = fans[name]
     err = g['error'] != 0
@@ -73,7 +73,7 @@ def test_gain(orc, fans, name):
             assert np.all(np.abs(G[g['sample_idx'][i]][m] - ref_s[m]) <= 1e-7 * np.maximum(1e-3, np.abs(ref_s[m])))
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy250'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
 def test_heatmap(orc, fans, name):
     g, env, rays = fans[name]
     good = [r for r in rays if r.status == 0]
