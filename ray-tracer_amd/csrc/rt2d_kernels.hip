@@ -1688,10 +1688,11 @@ __global__ void rt2d_hm_max_kernel(const double* H, int64_t size, unsigned long 
         double v = H[i];
         if (v != v) nan = true; else m = fmax(m, v);
     }
-    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off)); nan = nan || __shfl_xor((int)nan, off); }
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    const bool any_nan = __builtin_amdgcn_ballot_w64(nan) != 0ull;      // wave vote (inactive lanes count as false)
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&scratch[0], rt2d_order_key(m));
-        if (nan) atomicMax(&scratch[1], 1ull);
+        if (any_nan) atomicMax(&scratch[1], 1ull);
     }
 }
 
