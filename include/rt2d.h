@@ -287,6 +287,19 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
                                 const int32_t* res, const int32_t* shape,
                                 double* H, int64_t* n_dropped, int32_t* work, void* stream);
 
+/* rt2d_heatmap_accumulate for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and same map
+ * as rt2d_heatmap_accumulate called with a workspace, but the work list lives in a device array built into the library
+ * (4 MiB per GPU, held until the process ends), so the call allocates nothing: no hipMalloc, no hipFree, no allocating
+ * library routine.  Limit: n <= 1048576 rays (RT2D_NOALLOC_MAX_RAYS); more is rejected with an error, nothing is run.
+ * Every call on a GPU shares that GPU's list (its header words are cleared at the start of each call): calls that
+ * overlap on one GPU (different streams, different threads) race -- serialise them.  On return nothing is reported
+ * about the number of rays the general kernel handled (rt2d_heatmap_accumulate's work[0]). */
+int32_t rt2d_heatmap_accumulate_noalloc(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                        const int32_t* res, const int32_t* shape,
+                                        double* H, int64_t* n_dropped, void* stream);
+
 /* Heat-map presentation (reference: simulation.py:133-138): out[iz*nx + ix] = min(H/max(H), cutoff)^power.
  * scratch: device, at least 2 doubles. */
 int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, double reduction_power,

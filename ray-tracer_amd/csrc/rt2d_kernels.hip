@@ -2284,6 +2284,49 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
 }
 }  // extern "C++"
 
+// ------------------------------------------------------------------------------------------------------
+// rt2d_heatmap_accumulate for callers that cannot allocate: the work list of the tile kernel (a counter, a spare word and
+// one ray id per queued ray) lives in this file-scope device array instead of a caller-provided workspace.  Every GPU
+// the library runs on holds its own copy (4 MiB) until the process ends; host code only ever uses the per-device
+// address obtained from hipGetSymbolAddress, never the array's name.
+#define RT2D_NOALLOC_MAX_RAYS (1 << 20)
+static __device__ __align__(256) int32_t scratch[RT2D_NOALLOC_MAX_RAYS + 2];
+
+#define RT2D_MAX_DEVICES 64
+extern "C++" {
+static int32_t noalloc_scratch(int32_t** out) {
+    static std::mutex mu;
+    static int32_t* ptr[RT2D_MAX_DEVICES];          // per device: each GPU has its own copy of the array at its own address
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= RT2D_MAX_DEVICES) return fail("rt2d_heatmap_accumulate_noalloc: device %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr[dev]) {
+        void* p = nullptr;
+        HIP_OK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail("rt2d_heatmap_accumulate_noalloc: no device address for the scratch array");
+        ptr[dev] = (int32_t*)p;
+    }
+    *out = ptr[dev];
+    return 0;
+}
+}
+
+int32_t rt2d_heatmap_accumulate_noalloc(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                        const int32_t* res, const int32_t* shape,
+                                        double* H, int64_t* n_dropped, void* stream) {
+    if (n > RT2D_NOALLOC_MAX_RAYS)
+        return fail("rt2d_heatmap_accumulate_noalloc: %lld rays exceed the built-in work list of %d rays; "
+                    "use rt2d_heatmap_accumulate with a caller-provided workspace", (long long)n, RT2D_NOALLOC_MAX_RAYS);
+    int32_t* work = nullptr;
+    int32_t rc = noalloc_scratch(&work);
+    if (rc) return rc;
+    // the implementation zeroes the two header words of the list (hipMemsetAsync on `stream`) before the tile kernel fills
+    // it: nothing of the previous call's contents is read
+    return heatmap_accumulate_impl(X, Z, G, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream);
+}
+
 int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, double reduction_power,
                               double* out, double* scratch, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
