@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'librt2d_hip.so')
+SO_PATH = os.environ.get('RT2D_SO') or os.path.join(_HERE, 'librt2d_hip.so')      # RT2D_SO: an experimental build (development)
 SOURCES = [os.path.join(_HERE, 'csrc', 'rt2d_kernels.hip')]
 HEADERS = [os.path.join(_HERE, 'csrc', 'rt2d_device.h'), os.path.join(os.path.dirname(_HERE), 'include', 'rt2d.h')]
 

@@ -264,6 +264,8 @@ struct CastArgs {
     double inv_dx_max;            // RN(1 / dx_max), for rt2d_div_by_const
     double ceil_const;            // the surface depth when the surface table is constant (CEILC kernels)
     int32_t lanes;                // rays per wave (1..64, power of two): small fans are spread over more waves
+    unsigned long long* wave_log; // development aid (rt2d_debug_wave_log): per wave [start, end] of the 100 MHz clock and its hardware id
+    int64_t wave_log_cap;
     // fused cast -> gain -> heat map (FUSE kernels)
     const uint8_t* ray_mask;      // n bytes, 0 = leave this ray out
     BinTarget bin;
@@ -418,7 +420,26 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
     return out;
 }
 
-// WRITE: store the trajectory.  LDS_TABLES: step section of the blob staged in LDS.
+// Development aid: when a log buffer is set (rt2d_debug_wave_log), every wave records when it started and ended (100 MHz
+// clock) and where it ran; the destructor runs wherever the lane of the wave's first thread leaves the kernel.
+struct WaveLog {
+    unsigned long long* slot; unsigned long long t0;
+    __device__ __forceinline__ WaveLog(const CastArgs& a) : slot(nullptr), t0(0) {
+        if (a.wave_log == nullptr || (threadIdx.x & 63) != 0) return;
+        const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (w >= a.wave_log_cap) return;
+        slot = a.wave_log + 4 * w;
+        t0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ ~WaveLog() {
+        if (!slot) return;
+        slot[0] = t0; slot[1] = __builtin_amdgcn_s_memrealtime();
+        slot[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));          // HW_ID
+        slot[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));         // XCC_ID
+    }
+};
+
+// WRITE: store the trajectory.  TAB: where the step tables are read from (see the kernel).
 // POST: 0 = counts only (the counting pass of a stored cast); 1 = + bounding box of the ray (what the heat-map
 // pipeline needs); 2 = the whole scalar post-pass (L, T, target products; the decision margin when out.margin is set).
 // CUTOFF: opt-in termination on ray power (not in the reference, SURVEY trap 2): the gain of populate_NEW at
@@ -440,7 +461,7 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 #define RT2D_FUSE2_MAX_WAVES 8     // with the rebound losses precomputed (FUSE == 2): 216 registers; at 12 waves (168, ~30 words
                                    // spilled) the step itself is faster (10.7 vs 12.0 ms per 1M rays) but the deposits twice as slow
 #endif
-template <bool WRITE, bool LDS_TABLES, int POST, bool CUTOFF, bool CEILC, int FUSE = 0>
+template <bool WRITE, int TAB, int POST, bool CUTOFF, bool CEILC, int FUSE = 0>
 __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE : FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
@@ -450,21 +471,29 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         cold->dx_floor = a.env.dx_floor; cold->dx_ceil = a.env.dx_ceil; cold->out = a.out; cold->n = a.n;
         cold->rebound_cap = a.p.rebound_cap; cold->n_rebounds_max = a.p.n_rebounds_max;
     }
-    const double* tab;
-    const int n_stage = FUSE ? a.fuse_step_doubles : a.env.step_doubles;
-    if (LDS_TABLES) {
+    // TAB: where the step tables are read from.  1: the whole step section staged in LDS (small fans: one wave per CU, the
+    // LDS round trip is on the critical path of every step).  2: only the sound-speed table (the blob's first table, a few
+    // KB) in LDS, floor and surface through L1 / L2 (large fans: workgroups of a few waves, many per CU, so that the
+    // hardware refills every wave slot the moment a wave ends -- with the whole section in LDS a CU holds ONE workgroup
+    // of 16 waves, whose slots stay empty from the first wave that ends to the last).  0: everything through L1 / L2.
+    const double* tab_cz;       // sound speed
+    const double* tab_fl;       // floor and surface
+    const int n_stage = FUSE ? a.fuse_step_doubles : (TAB == 2 ? a.env.cz_doubles : a.env.step_doubles);
+    if (TAB != 0) {
         for (int i = threadIdx.x; i < n_stage; i += blockDim.x) s_tab[i] = a.blob[i];
-        tab = s_tab;
+        tab_cz = s_tab;
+        if (TAB == 2 && !FUSE) tab_fl = a.blob; else tab_fl = s_tab;
     } else {
-        tab = a.blob;
+        tab_cz = a.blob; tab_fl = a.blob;
     }
     double* s_abs = s_tab + n_stage;                       // FUSE: absorption table, then 8 x 64 slots per wave
     if (FUSE) {
         const double* src_abs = a.blob + a.env.gain_off + a.env.absorb.off;
         for (int i = threadIdx.x; i < a.fuse_abs_doubles; i += blockDim.x) s_abs[i] = src_abs[i];
     }
-    const double* tab_slope = FUSE ? a.blob : tab;         // where the slope tables are read from
+    const double* tab_slope = (FUSE || TAB == 2) ? a.blob : tab_fl;         // where the slope tables are read from
     __syncthreads();
+    WaveLog wave_log(a);
     // Ray of this lane.  A wave executes the rebound branch whenever ANY of its lanes rebounds, which with 64 rays is
     // most steps; a small fan therefore uses only `lanes` lanes of each wave and spreads over up to one wave per CU
     // (launch_cast2), so that a wave pays for its own few rebounds only.
@@ -514,7 +543,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     const bool has_target = FULL && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
     TargetTrack tt;
-    if (FULL || (WRITE && pc)) c_pt = rt2d_eval_c(tab, e.cz, z);          // C[0] = calc_c(z0), ray.py:273
+    if (FULL || (WRITE && pc)) c_pt = rt2d_eval_c(tab_cz, e.cz, z);          // C[0] = calc_c(z0), ray.py:273
     if (FULL) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
     if (WRITE && room > 0) { *px = x; *pz = z; if (pc) *pc = c_pt; }
     // running gain at the cut-off frequency
@@ -573,12 +602,12 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         const int jz = guess(e.cz, z_new, cz_jmax);
         double ra[4], rb[4], rz[8];
         {
-            auto pa = tab + e.floor.off + ja * 3;
-            auto pzr = tab + e.cz.off + jz * 7;
+            auto pa = tab_fl + e.floor.off + ja * 3;
+            auto pzr = tab_cz + e.cz.off + jz * 7;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ra[k] = pa[k];
             if (!CEILC) {
-                auto pb = tab + e.ceil.off + jb * 3;
+                auto pb = tab_fl + e.ceil.off + jb * 3;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rb[k] = pb[k];
             }
@@ -611,14 +640,14 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 if (out == 1 || out == 2) { stop = out; break; }
             }
             if (!(oka & okb)) {
-                ja = rt2d_fix_piece(tab, e.floor, xa, ja);
-                auto pa = tab + e.floor.off + ja * 3;
+                ja = rt2d_fix_piece(tab_fl, e.floor, xa, ja);
+                auto pa = tab_fl + e.floor.off + ja * 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ra[k] = pa[k];
                 z_floor = ra[1] * (xa - ra[0]) + ra[2];
                 if (!CEILC) {
-                    jb = rt2d_fix_piece(tab, e.ceil, xb, jb);
-                    auto pb = tab + e.ceil.off + jb * 3;
+                    jb = rt2d_fix_piece(tab_fl, e.ceil, xb, jb);
+                    auto pb = tab_fl + e.ceil.off + jb * 3;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) rb[k] = pb[k];
                     z_ceil = rb[1] * (xb - rb[0]) + rb[2];
@@ -631,7 +660,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
             const bool rebound = hit_floor || hit_ceil;
             if (rebound) {                                                    // ray.py:176-220
                 const DevTable slope_t = hit_floor ? cold->dx_floor : cold->dx_ceil;
-                double fx = hit_floor ? rt2d_eval_lin(tab, e.floor, x) : (CEILC ? a.ceil_const : rt2d_eval_lin(tab, e.ceil, x));
+                double fx = hit_floor ? rt2d_eval_lin(tab_fl, e.floor, x) : (CEILC ? a.ceil_const : rt2d_eval_lin(tab_fl, e.ceil, x));
                 x_new = x + (fx - z) / dx_z;          // closed-form root of surf(x) - dx_z*(x1 - x) - z (ray.py:177,200)
                 z_new = hit_floor ? z_floor : z_ceil;
                 bool ok;
@@ -681,7 +710,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 if (stop) break;
             }
             // the sound-speed record prefetched for z_new stands unless a rebound moved the point or the guess was off
-            if (rebound | !okz) rt2d_lookup<7>(tab, e.cz, z_new, rz);
+            if (rebound | !okz) rt2d_lookup<7>(tab_cz, e.cz, z_new, rz);
         }
 
         // accept the point (ray.py:235-247)
@@ -1855,15 +1884,19 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     const int64_t n = a.n;
     const size_t cold = ((sizeof(CastCold) + 15) / 16) * 16;
     const size_t tab_bytes = (size_t)env->dev.step_doubles * sizeof(double);
-    const bool in_lds = cold + tab_bytes <= RT2D_LDS_BUDGET;
-    const size_t lds = cold + (in_lds ? tab_bytes : 0);
+    const size_t cz_bytes = (size_t)env->dev.cz_doubles * sizeof(double);
+    static const int tab_env = getenv("RT2D_CAST_TAB") ? atoi(getenv("RT2D_CAST_TAB")) : -1;      // experiments: force a table mode
+    const bool in_lds = cold + tab_bytes <= RT2D_LDS_BUDGET && tab_env != 0;
+    static const int64_t n_cu_env = getenv("RT2D_CAST_CUS") ? atoll(getenv("RT2D_CAST_CUS")) : 0;
+    const int64_t n_cu = n_cu_env > 0 ? n_cu_env : env->n_cu;
+    // large fans (more than one full wave per CU): sound speed in LDS, floor and surface through the caches (TAB = 2)
+    const bool hybrid = n > n_cu * RT2D_WAVE && cold + cz_bytes <= 32 * 1024 && tab_env != 0 && tab_env != 1;
+    const size_t lds = cold + (hybrid ? cz_bytes : in_lds ? tab_bytes : 0);
     // Launch shape.  Measured on MI355X (tools/microbench_lanes.py): a wave steps fastest when it is alone on its CU
     // (co-resident waves cost each other 0.4-0.7 us per step even on different SIMDs) and when few of its lanes are in
     // use (a wave runs the rebound branch whenever ANY lane rebounds).  So: up to one wave per CU with as few rays per
     // wave as that allows; beyond 64 rays per wave, as many waves per workgroup as keeps every CU busy, at most 16
     // (1024 threads share one LDS copy of the tables).
-    static const int64_t n_cu_env = getenv("RT2D_CAST_CUS") ? atoll(getenv("RT2D_CAST_CUS")) : 0;
-    const int64_t n_cu = n_cu_env > 0 ? n_cu_env : env->n_cu;
     int block = RT2D_WAVE;
     a.lanes = RT2D_WAVE;
     if (n <= n_cu * RT2D_WAVE) {
@@ -1871,23 +1904,31 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
         while ((int64_t)lanes * n_cu < n) lanes *= 2;
         a.lanes = lanes;
     } else {
-        // smallest workgroup with which all workgroups are resident at once (LDS decides how many fit on a CU)
+        // smallest workgroup with which all workgroups are resident at once (LDS decides how many fit on a CU); with the
+        // small LDS footprint of the hybrid mode: two waves per workgroup, ten workgroups per CU
         const int64_t waves = (n + RT2D_WAVE - 1) / RT2D_WAVE;
         const int64_t per_cu = lds > 0 ? (int64_t)((160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1) : 16;
         int wpb = 1;
         while (wpb < 16 && (waves + wpb - 1) / wpb > n_cu * per_cu) wpb *= 2;
+        if (hybrid) wpb = 2;
+        if (const char* w = getenv("RT2D_CAST_WPB")) { const int v = atoi(w); if (v >= 1 && v <= 16) wpb = v; }
         block = wpb * RT2D_WAVE;
     }
     const int64_t rays_per_block = (int64_t)(block / RT2D_WAVE) * a.lanes;
     const int64_t grid = (n + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
-    if (in_lds) {
-        auto k = env->ceil_is_const ? rt2d_cast_kernel<WRITE, true, POST, CUTOFF, true> : rt2d_cast_kernel<WRITE, true, POST, CUTOFF, false>;
+    if (hybrid) {
+        auto k = env->ceil_is_const ? rt2d_cast_kernel<WRITE, 2, POST, CUTOFF, true> : rt2d_cast_kernel<WRITE, 2, POST, CUTOFF, false>;
+        a.ceil_const = env->ceil_const;
+        ALLOW_LDS(k, lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
+    } else if (in_lds) {
+        auto k = env->ceil_is_const ? rt2d_cast_kernel<WRITE, 1, POST, CUTOFF, true> : rt2d_cast_kernel<WRITE, 1, POST, CUTOFF, false>;
         a.ceil_const = env->ceil_const;
         ALLOW_LDS(k, lds);
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
     } else {
-        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, false, POST, CUTOFF, false>), dim3((unsigned)grid), dim3(block), lds, stream, a);
+        hipLaunchKernelGGL((rt2d_cast_kernel<WRITE, 0, POST, CUTOFF, false>), dim3((unsigned)grid), dim3(block), lds, stream, a);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -1928,6 +1969,12 @@ static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const
     return 0;
 }
 
+// development aid, not part of include/rt2d.h: waves of the following cast launches log [start, end, hw id, xcc id]
+// (4 words per wave) into `buf` (device, room for `cap` waves); NULL switches it off
+static unsigned long long* g_wave_log = nullptr;
+static int64_t g_wave_log_cap = 0;
+void rt2d_debug_wave_log(unsigned long long* buf, int64_t cap) { g_wave_log = buf; g_wave_log_cap = cap; }
+
 static CastArgs make_cast_args(rt2d_env_t env, const double* angles, int64_t n, const double* src, const Rt2dParams* p,
                                const double* init_slope, const double* init_mult, const Rt2dRayOut* out) {
     CastArgs a;
@@ -1936,6 +1983,7 @@ static CastArgs make_cast_args(rt2d_env_t env, const double* angles, int64_t n, 
     a.n = n; a.src_x = src[0]; a.src_z = src[1]; a.p = *p; a.out = *out;
     a.g_cut = p->power_cutoff > 0 ? 10 * log10(p->power_cutoff) : -INFINITY;
     a.inv_dx_max = 1.0 / p->dx_max;
+    a.wave_log = g_wave_log; a.wave_log_cap = g_wave_log_cap;
     return a;
 }
 
@@ -2002,8 +2050,8 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     const int64_t grid = (n + block - 1) / block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     a.fuse_loss = loss; a.fuse_loss_cap = loss ? loss_cap : 0;
-    auto k = loss ? (env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, 2> : rt2d_cast_kernel<false, true, 1, false, false, 2>)
-                  : (env->ceil_is_const ? rt2d_cast_kernel<false, true, 1, false, true, 1> : rt2d_cast_kernel<false, true, 1, false, false, 1>);
+    auto k = loss ? (env->ceil_is_const ? rt2d_cast_kernel<false, 1, 1, false, true, 2> : rt2d_cast_kernel<false, 1, 1, false, false, 2>)
+                  : (env->ceil_is_const ? rt2d_cast_kernel<false, 1, 1, false, true, 1> : rt2d_cast_kernel<false, 1, 1, false, false, 1>);
     ALLOW_LDS(k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());

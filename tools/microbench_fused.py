@@ -11,7 +11,11 @@ import bench
 rt = rt2d_loader.load()
 from ray_tracer_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-env = bench.make_env(rt)
+if os.environ.get('SWEEP_FLOOR_N'):
+    xs = np.linspace(0., 75000., int(os.environ['SWEEP_FLOOR_N']))
+    env = rt.Environment2D((xs, bench.c2_floor(xs)), (np.array([0., 75000.]), np.array([0., 0.])), np.array([0., -1501.]), np.array([75000., 1.]))
+else:
+    env = bench.make_env(rt)
 dev = torch.device('cuda', 0)
 angles = torch.from_numpy(-(np.arange(n) + 1) * (0.999 / n)).to(dev)
 fan = rt.RayFan(env, np.array([0., 0.]), angles, store=False, **bench.PROP)
