@@ -231,6 +231,15 @@ def one_step(rt, torch, env, source, angles_dev, stages=None, collectives=False,
     return total, n_pts, status, outp.view(int(shape[1]), int(shape[0]))
 
 
+def product_step(rt, env, source, angles, distributed=False):
+    """The hot path once THROUGH THE PRODUCT API, as a user of the reference's Simulation2D would write it
+    (simulation.py:69-94 cast, then the heat map): returns (fan, (nz, nx) device tensor)."""
+    sim = rt.Simulation2D(env, source, distributed=distributed)
+    fan = sim.cast(angles, **PROP)
+    hm = sim.heatmap(resolution=list(RES), cutoff=CUTOFF, reduction_power=.5, as_tensor=True)
+    return fan, hm
+
+
 def pmc_traffic(large):
     """HBM bytes per launch of the storing cast from the newest committed PMC profile (profiles/r*/*_traffic.json,
     written by tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command, with the
@@ -405,16 +414,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed step goes through the product classes (Simulation2D.cast + .heatmap): every rank hands the WHOLE fan of
+    # 999 N rays to cast(), which keeps this rank's share (ray j on rank j % N); heatmap() combines the ranks (C1, C2).
+    all_angles = -(np.arange(n_fan * world) + 1) / (1000.0 * world)
+    use_dist = world > 1 or args.force_collectives
+    if args.force_collectives and world == 1:
+        os.environ['RT2D_FORCE_COLLECTIVES'] = '1'
     for _ in range(args.warmup):
-        one_step(rt, torch, env, source, angles_dev, collectives=collectives, device=device)
-    stages = Stages(torch)
+        product_step(rt, env, source, all_angles, distributed=use_dist)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, n_pts, status, hm = one_step(rt, torch, env, source, angles_dev, stages=stages, collectives=collectives, device=device)
+        fan_p, hm = product_step(rt, env, source, all_angles, distributed=use_dist)
     barrier()
     dt = time.perf_counter() - t0
+    n_pts, status = fan_p.n_pts, fan_p.status
     steps_rank = ray_steps_of(n_pts, status)
+    # the same step spelled out call by call on the C ABI, for the per-stage HIP-event times (not the headline)
+    for _ in range(min(args.warmup, 2)):
+        one_step(rt, torch, env, source, angles_dev, collectives=collectives, device=device)
+    stages = Stages(torch)
+    barrier()
+    t0r = time.perf_counter()
+    for _ in range(args.steps):
+        _, n_pts_r, status_r, hm_r = one_step(rt, torch, env, source, angles_dev, stages=stages, collectives=collectives, device=device)
+    barrier()
+    dt_raw = time.perf_counter() - t0r
+    assert ray_steps_of(n_pts_r, status_r) == steps_rank and tuple(hm_r.shape) == tuple(hm.shape)
     t = torch.tensor([dt, float(steps_rank)], dtype=torch.float64, device=device)
     if world > 1:
         from ray_tracer_amd import parallel
@@ -441,6 +467,8 @@ def main():
                                    'floor max(-e^{0.0005x}-500,-1500+0.02x) over 75 km, gain @1 Hz, heat map 50x25 m, cutoff 0.5, reduction power 0.5',
                        'rays_per_gpu': n_fan, 'ray_steps_per_gpu': steps_rank, 'heatmap_shape': list(hm.shape)},
             's_per_heatmap': dt / args.steps,
+            'timed_path': 'product API: Simulation2D.cast + Simulation2D.heatmap (one device -> host read per heat map)',
+            'product_api_ms': ms_per_step, 'raw_abi_ms': dt_raw / args.steps * 1e3,
             'stage_ms': st,
             'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

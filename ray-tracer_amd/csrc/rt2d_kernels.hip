@@ -246,6 +246,17 @@ struct RayBinner {
     __device__ __forceinline__ void finish(const BinTarget& t, int lane) { leave(t, ok, false, lane); }
 };
 
+// Points of ray r that its tile has room for: every kernel that READS trajectories counts a ray's points through this, so
+// that a cast into a provisional layout whose room a ray outgrew (its n_pts counts on, its points beyond the room were
+// not stored, see rt2d_cast_write) can never make a later kernel read outside the tile -- the host finds out from
+// rt2d_fan_summary and casts again, possibly after such kernels were already queued.
+__device__ __forceinline__ int rt2d_stored_pts(const int32_t* n_pts, const int64_t* tile_off, int64_t r) {
+    const int64_t t = r >> 6;
+    const int64_t room = (tile_off[t + 1] - tile_off[t]) >> 6;
+    const int np = n_pts[r];
+    return (int)((int64_t)np < room ? (int64_t)np : room);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // stepping
 struct CastArgs {
@@ -921,7 +932,7 @@ __global__ void __launch_bounds__(256) rt2d_post_kernel(const PostArgs a) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n) return;
     const DevTable& cz = a.env.cz;
-    const int np = a.n_pts[r];
+    const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
     double xp = a.X[base], zp = a.Z[base];
     double cp = rt2d_eval_c(tab, cz, zp);
@@ -992,7 +1003,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     const int f0 = blockIdx.y * FCH;
     const int nf = min(FCH, a.n_freqs - f0);
     const DevTable& ab = a.env.absorb;
-    const int np = a.n_pts[r];
+    const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
 
     double fr[FCH], ff[FCH], S[FCH], A[FCH];
@@ -1096,8 +1107,10 @@ __global__ void __launch_bounds__(256) rt2d_gain_dg_kernel(const GainArgs a) {
     const int64_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t r = tile * RT2D_WAVE + lane;
-    const int np = (r < a.n) ? a.n_pts[r] : 0;
-    const int64_t t0 = a.tile_off[tile], len = a.tile_off[tile + 1] - t0;
+    const int np = (r < a.n) ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
+    int tmax = np;                                     // the tile's longest ray: a padded layout has more room than points
+    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+    const int64_t t0 = a.tile_off[tile], len = min(a.tile_off[tile + 1] - t0, (int64_t)tmax * RT2D_WAVE);
     const int f0 = blockIdx.z * FCH;
     const int nf = min(FCH, a.n_freqs - f0);
     double ff[FCH];
@@ -1151,7 +1164,12 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
     const int64_t r = tile * RT2D_WAVE + lane;
     const int fi = blockIdx.y;
     const int64_t t0 = a.tile_off[tile];
-    const int64_t len = a.tile_off[tile + 1] - t0;                          // 64 * steps of the longest ray of the tile
+    int64_t len = a.tile_off[tile + 1] - t0;                                // room of the tile ...
+    {                                                                       // ... cut to 64 * steps of its longest ray
+        int tmax = (r < a.n) ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
+        for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
+        len = min(len, (int64_t)max(tmax, 1) * RT2D_WAVE);
+    }
     double* G = a.G + (int64_t)fi * a.total + t0;
     // rebound losses of the tile's rays (ray.py:350-362): every (rebound, ray) pair on its own thread -- each costs a
     // handful of dependent loads, a sincos, a log10 -- then wave 0 turns them into running sums per ray
@@ -1172,7 +1190,7 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
         }
     }
     __syncthreads();
-    const int np = (r < a.n) ? a.n_pts[r] : 0;          // of the ray in this thread's column (lane == column for every element)
+    const int np = (r < a.n) ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;          // of the ray in this thread's column (lane == column for every element)
     if (scanner) {
         double A = 0.0;
         for (int k = 0; k < nreb; ++k) { A += s_loss[k * RT2D_WAVE + lane]; s_loss[k * RT2D_WAVE + lane] = A; }
@@ -1261,7 +1279,7 @@ __global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatAr
     if (!flags) return;
     const bool binme = (flags & 1) != 0;
     const DevTable& ab = a.env.absorb;
-    const int np = a.n_pts[r];
+    const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
     const double fr = b.freq;
     const double f = fr / 1000;                                            // model_absorption.py:32
@@ -1317,7 +1335,7 @@ __global__ void __launch_bounds__(256) rt2d_dist_kernel(const double* X, const d
                                                         const int32_t* n_pts, int64_t n, double tx, double tz, double* dist) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const int np = n_pts[r];
+    const int np = rt2d_stored_pts(n_pts, tile_off, r);
     const int64_t base = tile_off[r >> 6] + (r & 63);
     TargetTrack tt; tt.init();
     double mn = INFINITY, mx = -INFINITY;
@@ -1346,7 +1364,7 @@ __global__ void __launch_bounds__(64) rt2d_target_products_kernel(const TargetAr
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t r = a.ray_ids ? (int64_t)a.ray_ids[i] : i;
-    const int np = a.n_pts[r];
+    const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
     double best = INFINITY; int best_s = 0x7fffffff;
     for (int s = lane; s < np; s += RT2D_WAVE) {
@@ -1421,7 +1439,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     const uint8_t flags = (r < a.n) ? (a.ray_mask ? a.ray_mask[r] : (uint8_t)1) : (uint8_t)0;
     const bool mine = flags != 0;
     const bool hinted = (flags & 2) != 0;               // caller vouches for monotone columns and in-map points
-    int np = mine ? a.n_pts[r] : 0;
+    int np = mine ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
     const int64_t base = a.tile_off[tile] + lane;
     const int nx = (int)a.nx, nz = (int)a.nz;
     int tmax = np;
@@ -1599,7 +1617,7 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
     for (int64_t item = first_item; item < n_items; item += gridDim.x) {
         const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
         if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
-        const int np = a.n_pts[r];
+        const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
         const int64_t base = a.tile_off[r >> 6] + (r & 63);
         const bool cached = np <= a.cell_cap;
         auto cell_global = [&](int s) -> int32_t {
@@ -2318,7 +2336,8 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         while (split < max_split && n_tiles * split < 4096) split *= 2;    // enough waves to give every SIMD several
         a.split = split;
         const int64_t n_waves = n_tiles * split;
-        const int wpb = (n_waves <= 1024) ? 1 : 4;
+        static const int wpb_env = getenv("RT2D_HM_WPB") ? atoi(getenv("RT2D_HM_WPB")) : 0;
+        const int wpb = wpb_env > 0 ? wpb_env : ((n_waves <= 1024) ? 1 : 4);
         const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
         if (shape[1] <= 64) hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<1>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
         else hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<4>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);

@@ -39,9 +39,13 @@ def _all_reduce(t, op):
 
 
 def active():
-    """True inside an initialised process group of more than one rank."""
+    """True inside an initialised process group of more than one rank (RT2D_FORCE_COLLECTIVES=1: of any size, so that
+    the collectives can be rehearsed over RCCL on a single GPU)."""
+    import os
     dist = _dist()
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('RT2D_FORCE_COLLECTIVES') == '1'
 
 
 def shard_angles(angles, rank=None, world_size=None, mode='interleave'):
@@ -70,7 +74,7 @@ def allreduce_plot_range(range_min_plot, range_max_plot, device=None):
     dist = _dist()
     lo = np.asarray(range_min_plot, dtype=np.float64)
     hi = np.asarray(range_max_plot, dtype=np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not active():
         return lo.copy(), hi.copy()
     # one collective: max over (-min, max)
     t = torch.tensor(np.concatenate((-lo, hi)), dtype=torch.float64, device=device)
@@ -88,7 +92,7 @@ def heatmap_shape(range_min_plot, range_max_plot, res):
 def allreduce_heatmap(H):
     """C2: sum the per-rank heat maps in place (a torch tensor on this rank's device)."""
     dist = _dist()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         _all_reduce(H, dist.ReduceOp.SUM)
     return H
 

@@ -22,6 +22,7 @@ from . import _lib
 from ._lib import STOP_REASONS, RAY_ERR_INTERP
 
 TILE = 64
+_UNIFORM_LAYOUTS = {}            # (device, tiles, room) -> tile offsets of a uniform provisional layout (reused between casts)
 HEATMAP_FAST_MIN_RAYS = int(os.environ.get('RT2D_HEATMAP_FAST_MIN_RAYS', 6000))    # same switch as the library's
 SPECULATIVE_ROOM = 4096          # points per ray a speculative single-pass cast reserves
 SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below this
@@ -42,6 +43,22 @@ def _torch():
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+_FREQ_TENSORS = {}
+
+
+def _freq_tensor(freqs, device):
+    """Device tensor of a list of frequencies.  Kept between calls: creating it is a host -> device copy from pageable
+    memory, which waits for the stream -- the cast a heat map is queued behind -- before the gain can even be queued."""
+    key = (str(device), tuple(float(f) for f in freqs))
+    t = _FREQ_TENSORS.get(key)
+    if t is None:
+        import torch
+        t = torch.tensor(list(key[1]), dtype=torch.float64, device=device)
+        if len(_FREQ_TENSORS) < 256:
+            _FREQ_TENSORS[key] = t
+    return t
 
 
 class RayFan:
@@ -73,6 +90,10 @@ class RayFan:
         self.G = {}            # freq -> device tensor (total,) in tile layout
         self.G_end = {}        # freq -> device tensor (n,)
         self._post = None
+        self._pending = False      # a single-pass cast whose summary has not been read yet (validate())
+        self._force_exact = False
+        self._summary = None
+        self._init_host = init
         self._cast(init, store_c)
 
     # -- casting ----------------------------------------------------------------------------------
@@ -132,12 +153,14 @@ class RayFan:
 
             def alloc_log(out, cap):
                 self.rebound_cap = cap
-                self.reb_step = torch.full((cap, n), -1, **i32)
-                self.reb_surface = torch.zeros((cap, n), dtype=torch.uint8, device=dev)
-                self.reb_velocity = torch.zeros((cap, n), **f64)
-                self.reb_angle = torch.zeros((cap, n), **f64)
-                self.reb_pos_x = torch.zeros((cap, n), **f64)
-                self.reb_pos_z = torch.zeros((cap, n), **f64)
+                if cap * n <= (1 << 22):
+                    self.reb_step = torch.full((cap, n), -1, **i32)
+                    self.reb_surface = torch.zeros((cap, n), dtype=torch.uint8, device=dev)
+                    self.reb_velocity, self.reb_angle, self.reb_pos_x, self.reb_pos_z = (torch.zeros((cap, n), **f64) for _ in range(4))
+                else:            # big fans: entries beyond a ray's rebound count are never read, so no 800 MB of fills
+                    self.reb_step = torch.empty((cap, n), **i32)
+                    self.reb_surface = torch.empty((cap, n), dtype=torch.uint8, device=dev)
+                    self.reb_velocity, self.reb_angle, self.reb_pos_x, self.reb_pos_z = (torch.empty((cap, n), **f64) for _ in range(4))
                 out.reb_step, out.reb_surface = self.reb_step.data_ptr(), self.reb_surface.data_ptr()
                 out.reb_velocity, out.reb_angle = self.reb_velocity.data_ptr(), self.reb_angle.data_ptr()
                 out.reb_pos_x, out.reb_pos_z = self.reb_pos_x.data_ptr(), self.reb_pos_z.data_ptr()
@@ -172,61 +195,45 @@ class RayFan:
             total = C.c_int64(0)
 
             counted = False
-            # Small fans: ONE speculative storing pass into a provisional layout with the same generous room for every
-            # tile, then the exact layout and a compaction copy.  Valid when every ray fitted; otherwise (and for big
-            # fans, where the padding would cost too much memory) count -> layout -> store.
+            # ONE storing pass into a provisional layout with the same room for every tile (all of n_steps_max + 1 points
+            # when that is small, else SPECULATIVE_ROOM points per ray), which is then KEPT as the fan's layout: 288 GB of
+            # HBM make untouched room free, and the kernels that read trajectories never look past a ray's points.  Whether
+            # every ray fitted (and no rebound log overflowed) is known on the device right away (rt2d_fan_summary, queued
+            # behind the cast) but only READ when the host first needs a number of this fan (validate()): gain and heat
+            # map can be queued behind the cast without a round trip.  A fan that did not fit is cast again by the
+            # count -> layout -> store passes below.
             room = int(self.kw['n_steps_max']) + 1
             if n_tiles * room * TILE * 16 > SPECULATIVE_BYTES:
                 room = min(room, SPECULATIVE_ROOM)
             nrm = int(self.kw['n_rebounds_max'])
-            if n_tiles * room * TILE * 16 <= SPECULATIVE_BYTES:
+            layout_bytes = n_tiles * room * TILE * (24 if store_c else 16)
+            fits = layout_bytes <= SPECULATIVE_BYTES or (layout_bytes <= PADDED_BYTES and
+                                                         layout_bytes * 1.6 <= torch.cuda.mem_get_info(dev)[0])
+            if fits and not self._force_exact:
                 out = full_out()
                 alloc_log(out, nrm + 1 if nrm > -1 else REBOUND_LOG_CAP_DEFAULT)
-                off0 = torch.arange(n_tiles + 1, dtype=torch.int64, device=dev) * (room * TILE)
+                key = (dev.index, n_tiles, room)
+                off0 = _UNIFORM_LAYOUTS.get(key)
+                if off0 is None:
+                    off0 = torch.arange(n_tiles + 1, dtype=torch.int64, device=dev) * (room * TILE)
+                    if len(_UNIFORM_LAYOUTS) < 64:
+                        _UNIFORM_LAYOUTS[key] = off0
                 X0 = torch.empty(n_tiles * room * TILE, **f64)
                 Z0 = torch.empty(n_tiles * room * TILE, **f64)
                 C0 = torch.empty(n_tiles * room * TILE, **f64) if store_c else None
                 cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
-                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, self.tile_off.data_ptr(), None, stream))
-                # one kernel, one device -> host read: total points, longest tile, "a rebound log overflowed", plot range
-                tot, longest, log_full = self._summarise(self.tile_off, stream)
-                if longest <= room * TILE and not log_full:
-                    total.value = tot
-                    self.total = int(total.value)
-                    self.X = torch.empty(self.total, **f64)
-                    self.Z = torch.empty(self.total, **f64)
-                    self.Cpt = torch.empty(self.total, **f64) if store_c else None
-                    _lib.check(L.rt2d_traj_compact(off0.data_ptr(), self.tile_off.data_ptr(), n, X0.data_ptr(), Z0.data_ptr(),
-                                                   _ptr(C0), self.X.data_ptr(), self.Z.data_ptr(), _ptr(self.Cpt), stream))
-                    self._out = out
-                    self.passes = 'speculative'
-                    return
-                counted = not log_full                   # a ray outgrew the room: its points were still counted exactly
-                del X0, Z0, C0
-            else:
-                room_p = min(int(self.kw['n_steps_max']) + 1, SPECULATIVE_ROOM)
-                padded_bytes = n_tiles * room_p * TILE * (24 if store_c else 16)
-                if padded_bytes <= PADDED_BYTES and padded_bytes * 1.6 <= torch.cuda.mem_get_info(dev)[0]:
-                    out = full_out()
-                    alloc_log(out, nrm + 1 if nrm > -1 else REBOUND_LOG_CAP_DEFAULT)
-                    off0 = torch.arange(n_tiles + 1, dtype=torch.int64, device=dev) * (room_p * TILE)
-                    X0 = torch.empty(n_tiles * room_p * TILE, **f64)
-                    Z0 = torch.empty(n_tiles * room_p * TILE, **f64)
-                    C0 = torch.empty(n_tiles * room_p * TILE, **f64) if store_c else None
-                    cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
-                    exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
-                    _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
-                    _, longest, log_full = self._summarise(exact, stream)
-                    if longest <= room_p * TILE and not log_full:
-                        self.tile_off, self._tile_off_exact = off0, exact
-                        self.X, self.Z, self.Cpt = X0, Z0, C0
-                        self.total = n_tiles * room_p * TILE
-                        self._out = out
-                        self.padded = True
-                        self.passes = 'padded'
-                        return
-                    counted = not log_full
-                    del X0, Z0, C0
+                exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
+                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
+                self._queue_summary(exact, stream)
+                self.tile_off, self._tile_off_exact = off0, exact
+                self.X, self.Z, self.Cpt = X0, Z0, C0
+                self.total = n_tiles * room * TILE
+                self._room = room
+                self._out = out
+                self.padded = True
+                self.passes = 'padded' if layout_bytes > SPECULATIVE_BYTES else 'speculative'
+                self._pending = True
+                return
 
             # pass 1: count points and rebounds only (no post-pass, no stores) -- unless a single-pass attempt above
             # already did: it stops storing at its room but steps and counts to the end
@@ -247,16 +254,32 @@ class RayFan:
             cast_write(out, self.rebound_cap, self.tile_off, self.X, self.Z, self.Cpt)
             self._out = out
             self.passes = 'count+store'
+            self._queue_summary(self.tile_off, stream)
+            self._summary = self._summary_dev.tolist()
 
-    def _summarise(self, tile_off, stream):
-        """rt2d_fan_summary of the finished cast -> (total points, longest tile, rebound log overflowed); the whole
-        summary (with the plot range of the error-free rays) is kept for RayPack2D.add_fan."""
+    def _queue_summary(self, tile_off_exact, stream):
+        """rt2d_fan_summary of the finished cast, queued behind it; read by validate()."""
         torch = _torch()
-        summ = torch.empty(8, dtype=torch.float64, device=self.device)
+        self._summary_dev = torch.empty(8, dtype=torch.float64, device=self.device)
         _lib.check(_lib.lib().rt2d_fan_summary(self.status.data_ptr(), self.range.data_ptr(), None, self.n,
-                                               tile_off.data_ptr(), summ.data_ptr(), stream))
-        self._summary = summ.tolist()
-        return int(self._summary[0]), int(self._summary[1]), bool(self._summary[2])
+                                               tile_off_exact.data_ptr(), self._summary_dev.data_ptr(), stream))
+
+    def validate(self):
+        """The one device -> host read of a single-pass cast (64 bytes): [points of the exact layout, longest tile, a
+        rebound log overflowed, rays without error, plot range x 4].  If a ray outgrew the room of the provisional layout
+        or a rebound log overflowed, the fan is cast again with counted sizes (and anything derived from it is dropped).
+        Returns True when the fan had to be cast again."""
+        if not self._pending:
+            return False
+        self._pending = False
+        self._summary = self._summary_dev.tolist()
+        longest, log_full = int(self._summary[1]), bool(self._summary[2])
+        if longest <= self._room * TILE and not log_full:
+            return False
+        self._force_exact = True
+        self.G, self.G_end, self._post, self._host, self._scalars = {}, {}, None, {}, None
+        self._cast(self._init_host, self.Cpt is not None)
+        return True
 
     # -- scalars produced on demand ---------------------------------------------------------------
     def _lazy_scalars(self):
@@ -293,6 +316,7 @@ class RayFan:
     # -- host copies ------------------------------------------------------------------------------
     def host(self, name):
         """NumPy copy of a per-ray tensor (cached)."""
+        self.validate()
         h = self._host.get(name)
         if h is None:
             h = getattr(self, name).cpu().numpy()
@@ -315,6 +339,7 @@ class RayFan:
 
     def _ensure_compact(self):
         """Turns a padded layout (see PADDED_BYTES) into the exact one: X, Z, C and the gains kept so far are copied."""
+        self.validate()
         if not self.padded:
             return
         torch = _torch()
@@ -323,7 +348,7 @@ class RayFan:
             stream = torch.cuda.current_stream().cuda_stream
             f64 = dict(dtype=torch.float64, device=self.device)
             exact = self._tile_off_exact
-            total = int(exact[-1].item())
+            total = int(self._summary[0]) if self._summary is not None else int(exact[-1].item())
 
             def move(a, b, c=None):
                 na, nb = torch.empty(total, **f64), torch.empty(total, **f64)
@@ -346,10 +371,12 @@ class RayFan:
             self.X, self.Z, self.Cpt, self.G = X, Z, Cp, newG
             self.tile_off, self.total, self.padded = exact, total, False
             self._host.pop('tile_off', None)
-            self.passes = 'padded+compact'
+            self.passes = self.passes + '+compact'
+
     def ray_slice(self, tensor, i):
         """Points of ray i out of a tile-layout tensor (a strided device view, no copy)."""
         self._need_store()
+        self.validate()
         base = int(self.host('tile_off')[i // TILE]) + (i % TILE)
         return tensor[base::TILE][:int(self.host('n_pts')[i])]
 
@@ -402,12 +429,12 @@ class RayFan:
         new = [f for f in dict.fromkeys(freqs) if f not in self.G_end or (keep_arrays and f not in self.G)]
         if not new:
             return
-        if self.padded and keep_arrays and len(new) + len(self.G) > 1:
-            self._ensure_compact()               # the padded layout only has room for one gain array beside X and Z
+        if self.padded and keep_arrays and len(new) + len(self.G) > 1 and (len(new) + len(self.G)) * self.total * 8 > SPECULATIVE_BYTES:
+            self._ensure_compact()               # a big padded layout only has room for one gain array beside X and Z
         L = _lib.lib()
         with torch.cuda.device(self.device):
             f64 = dict(dtype=torch.float64, device=self.device)
-            fr = torch.tensor([float(f) for f in new], **f64)
+            fr = _freq_tensor(new, self.device)
             G = torch.empty((len(new), self.total), **f64) if keep_arrays else None
             G_end = torch.empty((len(new), self.n), **f64)
             # workspace for the rebound losses (their own kernel, see rt2d_gain) while it stays modest
@@ -481,7 +508,7 @@ class RayFan:
                 # the rebound losses at this frequency from the count pass's log, by their own kernel (rt2d_rebound_loss)
                 cap = self.rebound_cap
                 loss = torch.empty(cap * self.n, dtype=torch.float64, device=self.device)
-                fr = torch.tensor([float(freq)], dtype=torch.float64, device=self.device)
+                fr = _freq_tensor([freq], self.device)
                 _lib.check(L.rt2d_rebound_loss(handle, C.byref(self._out), cap, self.n, fr.data_ptr(), 1, loss.data_ptr(), stream))
             rc = L.rt2d_cast_heatmap(handle, self.angles_dev.data_ptr(), self.n, src,
                                      C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
@@ -533,6 +560,20 @@ class RayFan:
             self.last_slow_rays = n_rest
             self.last_fused_violations = viol
 
+    @property
+    def last_slow_rays(self):
+        """Rays of the last heatmap_accumulate* call that went through the general (one workgroup per ray) kernel."""
+        v = getattr(self, '_last_slow', 0)
+        if not isinstance(v, int):
+            q = int(v[0].item())              # work[0] of rt2d_heatmap_accumulate: -1 = the tile kernel was not used
+            v = self.n if q < 0 else q
+            self._last_slow = v
+        return v
+
+    @last_slow_rays.setter
+    def last_slow_rays(self, v):
+        self._last_slow = int(v)
+
     def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True, stream=None):
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
         fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests).
@@ -558,8 +599,7 @@ class RayFan:
                                                  self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
                                                  _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),
                                                  torch.cuda.current_stream().cuda_stream))
-            queued = int(work[0].item()) if fast else -1
-            self.last_slow_rays = self.n if queued < 0 else queued      # rays binned by the general kernel
+            self._last_slow = work if fast else self.n                   # rays binned by the general kernel: read on demand
 
 
 class _LinearPath:
@@ -803,27 +843,50 @@ class RayPack2D:
     per-ray objects (``add_fan``); ``rays``, ``angles``, ``stop_reasons`` and ``dist`` are built lazily."""
 
     def __init__(self):
-        self.rays = _RayList()
+        self._rays = _RayList()
         self.freqs = list()
-        self.n_rays, self.n_angles, self.n_freqs = 0, 0, 0
-        self.range_min_plot = np.zeros(2)
-        self.range_max_plot = np.zeros(2)
-        self.size_plot = np.zeros(2)
-        self.dist_sorted = None
+        self._n_rays, self._n_angles, self.n_freqs = 0, 0, 0
+        self._range_min_plot = np.zeros(2)
+        self._range_max_plot = np.zeros(2)
+        self._size_plot = np.zeros(2)
+        self._dist_sorted = None
         self._angle_set = set()          # angles of rays added one by one
         self._angle_blocks = []          # sorted angle arrays of the fans added whole
         self._dist_keys = []
         self._maps = None
-        self.n_failed = 0        # rays whose status was an error and that were therefore not added
+        self._n_failed = 0       # rays whose status was an error and that were therefore not added
+        self._pending = []       # fans added but not yet folded in (add_fan): (fan, indices)
+
+    # The reference's attributes.  Whole fans are folded in on first use (_resolve): casting a fan must not wait for the
+    # device, and a heat map needs none of this on the host (Simulation2D.heatmap).
+    def _resolve(self):
+        while self._pending:
+            fan, indices = self._pending.pop(0)
+            self._add_fan_now(fan, indices)
+
+    def _sole_pending_fan(self):
+        """The fan, if this pack is exactly one whole fan that has not been folded in yet (else None)."""
+        if len(self._pending) == 1 and self._pending[0][1] is None and self._n_rays == 0 and not len(self._rays):
+            return self._pending[0][0]
+        return None
+
+    rays = property(lambda self: (self._resolve(), self._rays)[1])
+    n_rays = property(lambda self: (self._resolve(), self._n_rays)[1])
+    n_angles = property(lambda self: (self._resolve(), self._n_angles)[1])
+    n_failed = property(lambda self: (self._resolve(), self._n_failed)[1])
+    range_min_plot = property(lambda self: (self._resolve(), self._range_min_plot)[1])
+    range_max_plot = property(lambda self: (self._resolve(), self._range_max_plot)[1])
+    size_plot = property(lambda self: (self._resolve(), self._size_plot)[1])
+    dist_sorted = property(lambda self: (self._resolve(), self._dist_sorted)[1])
 
     def __repr__(self):
         return f'Raypack containing {self.n_rays} rays cast with {self.n_angles} angles'
 
     def _fold_range(self, rmin, rmax):
         # ray.py:466-472: starts from zeros, so the origin is always inside the plot range
-        self.range_min_plot = np.minimum(self.range_min_plot, rmin)
-        self.range_max_plot = np.maximum(self.range_max_plot, rmax)
-        self.size_plot = self.range_max_plot - self.range_min_plot
+        self._range_min_plot = np.minimum(self._range_min_plot, rmin)
+        self._range_max_plot = np.maximum(self._range_max_plot, rmax)
+        self._size_plot = self._range_max_plot - self._range_min_plot
 
     def _known_angles(self, a):
         """Boolean mask: which of the angles `a` the pack already holds."""
@@ -840,14 +903,19 @@ class RayPack2D:
         return known
 
     def add_fan(self, fan, indices=None):
-        """Add rays of a fan (all, or the given indices), skipping errored rays and angles already present."""
+        """Add rays of a fan (all, or the given indices), skipping errored rays and angles already present.  The fan is
+        folded in when the pack is first looked at."""
+        self._pending.append((fan, None if indices is None else np.asarray(indices, dtype=np.int64)))
+        self._maps = None
+
+    def _add_fan_now(self, fan, indices=None):
         ang = np.asarray(fan.angles, dtype=np.float64)
         status = fan.host('status')
         idx_all = np.arange(fan.n) if indices is None else np.asarray(indices, dtype=np.int64)
         # whole-array form of the reference's per-ray loop (ray.py:451-465): errored rays are left out, an angle is kept
         # the first time it is seen (a million-ray fan must not spend a second in a Python loop here)
         ok = status[idx_all] != RAY_ERR_INTERP
-        self.n_failed += int((~ok).sum())
+        self._n_failed += int((~ok).sum())
         cand = idx_all[ok]
         a = ang[cand]
         step = np.diff(a)
@@ -869,9 +937,9 @@ class RayPack2D:
         if not len(keep):
             return
         keep = np.asarray(keep, dtype=np.int64)
-        self.rays._add_segment(fan, keep)
-        self.n_rays += len(keep)
-        self.n_angles += len(keep)
+        self._rays._add_segment(fan, keep)
+        self._n_rays += len(keep)
+        self._n_angles += len(keep)
         summ = getattr(fan, '_summary', None)
         if summ is not None and len(keep) == fan.n and int(summ[3]) == fan.n:
             lo_hi = np.array([-summ[4], -summ[5], summ[6], summ[7]])     # every ray kept and error-free: the cast's own fold
@@ -891,17 +959,18 @@ class RayPack2D:
         self._maps = None
 
     def add(self, *rays):
+        self._resolve()
         for ray in rays:
             if ray.angle in self._angle_set or self._known_angles(ray.angle)[0]:
                 continue
             self._angle_set.add(ray.angle)
             if ray._fan is not None:
-                self.rays._add_segment(ray._fan, np.array([ray._i], dtype=np.int64))
-                self.rays._made[len(self.rays) - 1] = ray
+                self._rays._add_segment(ray._fan, np.array([ray._i], dtype=np.int64))
+                self._rays._made[len(self._rays) - 1] = ray
             else:
-                self.rays._add_segment(None, [ray])
-            self.n_rays += 1
-            self.n_angles += 1
+                self._rays._add_segment(None, [ray])
+            self._n_rays += 1
+            self._n_angles += 1
             self._fold_range(ray.range_min, ray.range_max)
             d = ray.dist_to_target
             self._dist_keys.append(np.array([np.nan if d is None else d], dtype=np.float64))
@@ -910,7 +979,7 @@ class RayPack2D:
 
     def _update_dist_sorted(self):
         if self._dist_keys:
-            self.dist_sorted = np.sort(np.unique(np.concatenate(self._dist_keys)))   # unique keeps a single NaN, like dict keys of one None
+            self._dist_sorted = np.sort(np.unique(np.concatenate(self._dist_keys)))   # unique keeps a single NaN, like dict keys of one None
 
     def _build_maps(self):
         if self._maps is None:
@@ -936,10 +1005,12 @@ class RayPack2D:
 
     def segments(self):
         """[(fan, index array)] of the fan-backed rays, for batched device work."""
-        return [(fan, idx) for fan, idx in self.rays._segments if fan is not None]
+        self._resolve()
+        return [(fan, idx) for fan, idx in self._rays._segments if fan is not None]
 
     def populate(self, *freqs):
-        for fan, _ in self.segments():
+        fans = [f for f, _ in self._pending] if self._pending and not len(self._rays) else [f for f, _ in self.segments()]
+        for fan in fans:
             fan.populate(*freqs)
         for f in freqs:
             if f not in self.freqs:

@@ -79,19 +79,79 @@ class Simulation2D:
         raypack.add_fan(fan)
         return fan
 
-    def heatmap_full(self, **kwargs):
-        """Un-normalised heat map (nx, nz) as a device tensor, plus the number of dropped points."""
-        torch = _torch()
+    @staticmethod
+    def _resolution(kwargs):
         res = np.asarray(kwargs.get('resolution', np.array([50, 25])))
         if not np.issubdtype(res.dtype, np.integer):
             if np.any(res != np.round(res)):
                 raise TypeError('heatmap resolution must be integral (the reference floor-divides integer coordinates)')
             res = res.astype(np.int64)
+        return res
+
+    def _heatmap_one_fan(self, fan, res, kwargs, finalize):
+        """Heat map of a pack that is ONE whole fan, without waiting for the device before the end: the map is binned
+        into the shape of the environment's rectangle (an upper bound of the plot range, known on the host), normalised
+        there, and cropped to ceil(size_plot / res) + 1 (simulation.py:117) once the fan's summary -- plot range, "every
+        ray fitted its room" -- has been read, in the one device -> host read of the whole cast + heat map.  Valid when
+        no ray starts left of x = 0 or rises above z = 1 (then every point falls inside both maps, at the same cell);
+        returns None otherwise, or when the fan had to be cast again, and the caller takes the general path."""
+        torch = _torch()
+        env = self.env
+        lo = np.minimum(0., np.asarray(env.range_min, dtype=np.float64))
+        hi = np.maximum(0., np.asarray(env.range_max, dtype=np.float64))
+        if lo[0] <= -1 or hi[1] >= 1 + 1e-9 or fan.n == 0 or not fan._pending:
+            return None
+        shape_b = parallel.heatmap_shape(lo, hi, res)
+        if int(shape_b[0]) * int(shape_b[1]) >= (1 << 28):
+            return None
+        device = fan.device
+        with torch.cuda.device(device):
+            a = fan.angles_dev
+            distinct = ((a[1:] > a[:-1]).all() | (a[1:] < a[:-1]).all()) if fan.n > 1 else None
+            H = torch.zeros(int(shape_b[0]) * int(shape_b[1]), dtype=torch.float64, device=device)
+            dropped = torch.zeros(1, dtype=torch.int64, device=device)
+            mask = (fan.status == 0).to(torch.uint8)
+            fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
+                                   fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
+            out_b = None
+            if finalize:
+                out_b = torch.empty((int(shape_b[1]), int(shape_b[0])), dtype=torch.float64, device=device)
+                scratch = torch.empty(2, dtype=torch.float64, device=device)
+                shape_c = (C.c_int32 * 2)(int(shape_b[0]), int(shape_b[1]))
+                _lib.check(_lib.lib().rt2d_heatmap_finalize(H.data_ptr(), shape_c, float(kwargs.get('cutoff', .02)),
+                                                            float(kwargs.get('reduction_power', .5)), out_b.data_ptr(),
+                                                            scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            # -- the one read --
+            if fan.validate():
+                return None                                   # cast again with counted sizes: start over
+            if distinct is not None and not bool(distinct.item()):
+                return None                                   # repeated angles: the pack keeps the first of each
+        summ = fan._summary
+        rmin, rmax = -np.array(summ[4:6]), np.array(summ[6:8])
+        if rmin[0] <= -1 or rmax[1] >= 1:
+            return None
+        shape = parallel.heatmap_shape(rmin, rmax, res)
+        return H.view(int(shape_b[0]), int(shape_b[1])), out_b, shape, dropped
+
+    def heatmap_full(self, **kwargs):
+        """Un-normalised heat map (nx, nz) as a device tensor, plus the number of dropped points."""
+        return self._heatmap(kwargs, finalize=False)
+
+    def _heatmap(self, kwargs, finalize):
+        torch = _torch()
+        res = self._resolution(kwargs)
         freq = kwargs.get('freq', 1)
         raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
+        dist_on = getattr(raypack, 'sharded', False) and parallel.active()
+        fan = raypack._sole_pending_fan()
+        if fan is not None and fan.store and not dist_on and not kwargs.get('stream', None):
+            got = self._heatmap_one_fan(fan, res, kwargs, finalize)
+            if got is not None:
+                Hb, out_b, shape, dropped = got
+                nx, nz = int(shape[0]), int(shape[1])
+                return (out_b[:nz, :nx] if finalize else Hb[:nx, :nz]), dropped
         segs = raypack.segments()
         device = segs[0][0].device if segs else torch.device('cuda', torch.cuda.current_device())
-        dist_on = getattr(raypack, 'sharded', False) and parallel.active()
         if dist_on:                                                       # C1: the plot range of ALL ranks' rays
             lo, hi = parallel.allreduce_plot_range(raypack.range_min_plot, raypack.range_max_plot, device=device)
             shape = parallel.heatmap_shape(lo, hi, res)
@@ -109,7 +169,18 @@ class Simulation2D:
         if dist_on:                                                       # C2: sum of the ranks' maps
             parallel.allreduce_heatmap(H)
             parallel._all_reduce(dropped, parallel._dist().ReduceOp.SUM)
-        return H.view(int(shape[0]), int(shape[1])), dropped
+        H = H.view(int(shape[0]), int(shape[1]))
+        if not finalize:
+            return H, dropped
+        nx, nz = H.shape
+        out = torch.empty((nz, nx), dtype=torch.float64, device=H.device)
+        scratch = torch.empty(2, dtype=torch.float64, device=H.device)
+        shape_c = (C.c_int32 * 2)(int(nx), int(nz))
+        with torch.cuda.device(H.device):
+            _lib.check(_lib.lib().rt2d_heatmap_finalize(H.data_ptr(), shape_c, float(kwargs.get('cutoff', .02)),
+                                                        float(kwargs.get('reduction_power', .5)), out.data_ptr(),
+                                                        scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out, dropped
 
     def heatmap(self, **kwargs):
         """Ray-power heat map (reference: commented block simulation.py:96-138).
@@ -122,16 +193,7 @@ class Simulation2D:
         :param kwargs/as_tensor: return the device tensor instead of a NumPy array
         Returns the (nz, nx) map, i.e. ``heatmap_plot.T``.
         """
-        torch = _torch()
-        H, _ = self.heatmap_full(**kwargs)
-        nx, nz = H.shape
-        out = torch.empty((nz, nx), dtype=torch.float64, device=H.device)
-        scratch = torch.empty(2, dtype=torch.float64, device=H.device)
-        shape_c = (C.c_int32 * 2)(int(nx), int(nz))
-        with torch.cuda.device(H.device):
-            _lib.check(_lib.lib().rt2d_heatmap_finalize(H.data_ptr(), shape_c, float(kwargs.get('cutoff', .02)),
-                                                        float(kwargs.get('reduction_power', .5)), out.data_ptr(),
-                                                        scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        out, _ = self._heatmap(kwargs, finalize=True)
         return out if kwargs.get('as_tensor', False) else out.cpu().numpy()
 
     def heatmaps(self, freqs, **kwargs):
