@@ -119,17 +119,28 @@ class RayFan:
             stream = torch.cuda.current_stream().cuda_stream
             f64 = dict(dtype=torch.float64, device=dev)
             i32 = dict(dtype=torch.int32, device=dev)
-            self.n_pts = torch.empty(n, **i32)
-            self.stop_code = torch.empty(n, **i32)
-            self.n_rebounds = torch.empty(n, **i32)
-            self.status = torch.empty(n, **i32)
-            self.range = torch.empty((4, n), **f64)
-            self.monotone = torch.empty(n, dtype=torch.uint8, device=dev)
-            self.slope_max = torch.empty(n, **f64)
+            # every per-ray result out of ONE allocation (a dozen small ones cost the host more than the cast's launch)
+            n8 = (n + 7) // 8 * 8
+            buf = torch.empty(8 * n8 * 8, dtype=torch.uint8, device=dev)          # 5 doubles + 4 ints + 1 byte per ray, rounded up
+
+            def carve(first_double, count, dtype):
+                nbytes = count * {torch.float64: 8, torch.int32: 4, torch.uint8: 1}[dtype]
+                return buf[first_double * 8:first_double * 8 + nbytes].view(dtype)
+
+            self.range = carve(0, 4 * n, torch.float64).view(4, n)
+            self.slope_max = carve(4 * n8, n, torch.float64)
+            self.n_pts = carve(5 * n8, n, torch.int32)
+            self.stop_code = carve(5 * n8 + n8 // 2, n, torch.int32)
+            self.n_rebounds = carve(6 * n8, n, torch.int32)
+            self.status = carve(6 * n8 + n8 // 2, n, torch.int32)
+            self.monotone = carve(7 * n8, n, torch.uint8)
             self._scalars = None
-            self.dist = torch.full((n,), float('nan'), **f64)
-            self.step_target = torch.full((n,), -1, **i32)
-            self.T_target = torch.full((n,), float('nan'), **f64)
+            if self.target is not None:
+                self.dist = torch.full((n,), float('nan'), **f64)
+                self.step_target = torch.full((n,), -1, **i32)
+                self.T_target = torch.full((n,), float('nan'), **f64)
+            else:
+                self.dist = self.step_target = self.T_target = None
             init_slope = init_mult = None
             if init is not None:
                 init_slope = torch.as_tensor(np.ascontiguousarray(init[0], dtype=np.float64)).to(dev)
@@ -152,15 +163,21 @@ class RayFan:
                 return out
 
             def alloc_log(out, cap):
+                # the rebound log: entry k of ray r at [k, r]; entries beyond a ray's rebound count are unspecified (never
+                # read: no fills -- 800 MB of them for a 1M-ray fan); one allocation
                 self.rebound_cap = cap
-                if cap * n <= (1 << 22):
-                    self.reb_step = torch.full((cap, n), -1, **i32)
-                    self.reb_surface = torch.zeros((cap, n), dtype=torch.uint8, device=dev)
-                    self.reb_velocity, self.reb_angle, self.reb_pos_x, self.reb_pos_z = (torch.zeros((cap, n), **f64) for _ in range(4))
-                else:            # big fans: entries beyond a ray's rebound count are never read, so no 800 MB of fills
-                    self.reb_step = torch.empty((cap, n), **i32)
-                    self.reb_surface = torch.empty((cap, n), dtype=torch.uint8, device=dev)
-                    self.reb_velocity, self.reb_angle, self.reb_pos_x, self.reb_pos_z = (torch.empty((cap, n), **f64) for _ in range(4))
+                m = cap * n
+                m8 = (m + 7) // 8 * 8
+                lb = torch.empty((4 * m8 + m8 // 2 + m8 // 8) * 8, dtype=torch.uint8, device=dev)
+
+                def part(first_double, dtype):
+                    nbytes = m * {torch.float64: 8, torch.int32: 4, torch.uint8: 1}[dtype]
+                    return lb[first_double * 8:first_double * 8 + nbytes].view(dtype).view(cap, n)
+
+                self.reb_velocity, self.reb_angle = part(0, torch.float64), part(m8, torch.float64)
+                self.reb_pos_x, self.reb_pos_z = part(2 * m8, torch.float64), part(3 * m8, torch.float64)
+                self.reb_step = part(4 * m8, torch.int32)
+                self.reb_surface = part(4 * m8 + m8 // 2, torch.uint8)
                 out.reb_step, out.reb_surface = self.reb_step.data_ptr(), self.reb_surface.data_ptr()
                 out.reb_velocity, out.reb_angle = self.reb_velocity.data_ptr(), self.reb_angle.data_ptr()
                 out.reb_pos_x, out.reb_pos_z = self.reb_pos_x.data_ptr(), self.reb_pos_z.data_ptr()

@@ -106,8 +106,17 @@ class Simulation2D:
             return None
         device = fan.device
         with torch.cuda.device(device):
-            a = fan.angles_dev
-            distinct = ((a[1:] > a[:-1]).all() | (a[1:] < a[:-1]).all()) if fan.n > 1 else None
+            # a pack keeps the first ray of every angle (ray.py:454): a strictly monotonic sweep has no repeats.  Checked on
+            # the host copy of the angles when there is one (while the device is busy with the cast), else on the device
+            distinct = None
+            if fan.n > 1:
+                if fan._angles_host is not None:
+                    step = np.diff(fan._angles_host)
+                    if not (bool((step > 0).all()) or bool((step < 0).all())):
+                        return None
+                else:
+                    a = fan.angles_dev
+                    distinct = (a[1:] > a[:-1]).all() | (a[1:] < a[:-1]).all()
             H = torch.zeros(int(shape_b[0]) * int(shape_b[1]), dtype=torch.float64, device=device)
             dropped = torch.zeros(1, dtype=torch.int64, device=device)
             mask = (fan.status == 0).to(torch.uint8)
