@@ -97,27 +97,45 @@ def allreduce_heatmap(H):
     return H
 
 
-def allgather_topk(dist_local, angles_local, k):
-    """C3 (sweep + refine): the k globally smallest distances and their angles.  Each rank contributes its own
-    k best (NaN = never reaches the target abscissa) and the merge is done redundantly on every rank."""
+def allgather_topk(dist_local, angles_local, k, index_local=None):
+    """C3 (sweep + refine): the rays whose distance is among the k smallest DISTINCT distances of the whole fan -- the
+    reference's selection rule (simulation.py:241-249: it keys its rays by distance and keeps the k smallest keys, so rays
+    at equal distance stay together) -- sorted by distance, equal distances in fan order.  Each rank contributes the rays
+    within ITS k smallest distinct distances (a superset of its share of the answer; NaN = never reaches the target
+    abscissa), the candidates are all-gathered (padded to the largest contribution) and the rule is applied again on every
+    rank.  index_local: the rays' positions in the whole fan (shard_angles' second result), used to order ties; None = the
+    local positions.  Returns (distances, angles)."""
     import torch
     dist = _dist()
     d = torch.as_tensor(dist_local, dtype=torch.float64)
     a = torch.as_tensor(angles_local, dtype=torch.float64, device=d.device)
-    d = torch.where(torch.isnan(d), torch.full_like(d, float('inf')), d)
-    kk = min(k, d.numel())
-    best = torch.topk(d, kk, largest=False)
-    cand = torch.full((2, k), float('inf'), dtype=torch.float64, device=d.device)
-    cand[0, :kk] = best.values
-    cand[1, :kk] = a[best.indices]
+    idx = torch.arange(d.numel(), device=d.device) if index_local is None else torch.as_tensor(index_local, device=d.device)
+    idx = idx.to(torch.float64)                                   # exact below 2^53; travels in the same tensor
+
+    def select(dd, aa, ii):
+        valid = ~torch.isnan(dd)
+        if not bool(valid.any()):
+            return dd[:0], aa[:0], ii[:0]
+        uniq = torch.unique(dd[valid])                            # ascending
+        kth = uniq[min(k, uniq.numel()) - 1]
+        sel = torch.nonzero(valid & (dd <= kth)).flatten()
+        order = torch.argsort(ii[sel], stable=True)               # fan order first ...
+        sel = sel[order]
+        sel = sel[torch.argsort(dd[sel], stable=True)]            # ... then by distance, stable: ties stay in fan order
+        return dd[sel], aa[sel], ii[sel]
+
+    d, a, idx = select(d, a, idx)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dev = cand.device
+        dev = d.device
+        count = torch.tensor([d.numel()], dtype=torch.int64, device=dev)
+        _all_reduce(count, dist.ReduceOp.MAX)
+        m = int(count.item())
+        cand = torch.full((3, m), float('nan'), dtype=torch.float64, device=dev)
+        cand[0, :d.numel()], cand[1, :d.numel()], cand[2, :d.numel()] = d, a, idx
         if cand.is_cuda and dist.get_backend() == 'gloo':
             cand = cand.cpu()
         parts = [torch.empty_like(cand) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, cand)
         cand = torch.cat(parts, dim=1).to(dev)
-    order = torch.argsort(cand[0], stable=True)[:k]
-    out_d, out_a = cand[0, order], cand[1, order]
-    keep = torch.isfinite(out_d)
-    return out_d[keep], out_a[keep]
+        d, a, idx = select(cand[0], cand[1], cand[2])
+    return d, a

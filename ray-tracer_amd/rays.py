@@ -109,7 +109,7 @@ class RayFan:
         p.power_cutoff, p.cutoff_freq = float(self.kw['power_cutoff']), float(self.kw['cutoff_freq'])
         return p
 
-    def _cast(self, init, store_c):
+    def _cast(self, init, store_c, known_n_pts=None):
         torch = _torch()
         kwargs_keep_log = self.keep_log
         L = _lib.lib()
@@ -226,7 +226,10 @@ class RayFan:
             layout_bytes = n_tiles * room * TILE * (24 if store_c else 16)
             fits = layout_bytes <= SPECULATIVE_BYTES or (layout_bytes <= PADDED_BYTES and
                                                          layout_bytes * 1.6 <= torch.cuda.mem_get_info(dev)[0])
-            if fits and not self._force_exact:
+            if known_n_pts is not None:
+                self.n_pts.copy_(known_n_pts)        # point counts from an earlier cast of these rays: no counting pass
+                counted = True
+            elif fits and not self._force_exact:
                 out = full_out()
                 alloc_log(out, nrm + 1 if nrm > -1 else REBOUND_LOG_CAP_DEFAULT)
                 key = (dev.index, n_tiles, room)
@@ -264,7 +267,11 @@ class RayFan:
             self.total = int(total.value)
             # pass 2: store trajectories, the rebound log and the post-pass scalars
             out = full_out()
-            alloc_log(out, max(1, int(self.n_rebounds.max().item())))
+            if known_n_pts is not None:
+                nrm_k = int(self.kw['n_rebounds_max'])
+                alloc_log(out, nrm_k + 1 if nrm_k > -1 else REBOUND_LOG_CAP_DEFAULT)
+            else:
+                alloc_log(out, max(1, int(self.n_rebounds.max().item())))
             self.X = torch.empty(self.total, **f64)
             self.Z = torch.empty(self.total, **f64)
             self.Cpt = torch.empty(self.total, **f64) if store_c else None
@@ -352,7 +359,44 @@ class RayFan:
 
     def _need_store(self):
         if not self.store:
-            raise _lib.Rt2dError('this fan was cast with store=False: trajectories were not kept')
+            if not getattr(self, '_lazy_store', False):
+                raise _lib.Rt2dError('this fan was cast with store=False: trajectories were not kept')
+            # a subset of a scalars-only fan (subset()): its trajectories are cast now, in ONE storing pass -- the point
+            # counts are already known, so the exact layout can be built before the pass
+            known = self.n_pts
+            self.store, self._lazy_store = True, False
+            self._host = {}
+            self._cast(self._init_host, False, known_n_pts=known)
+
+    def subset(self, indices):
+        """The rays `indices` of a fan cast with store=False as a fan of their own: per-ray scalars are copied, nothing is
+        cast; the trajectories are cast (once, with the known point counts) if anything asks for them.  The stepping
+        kernel is deterministic, so a ray cast again is the same ray."""
+        torch = _torch()
+        if self.store:
+            raise _lib.Rt2dError('subset() is for fans cast with store=False')
+        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=self.device)
+        sub = object.__new__(RayFan)
+        sub.env, sub.source, sub.target, sub.device, sub.kw = self.env, self.source, self.target, self.device, dict(self.kw)
+        sub.store, sub.keep_log, sub._lazy_store = False, False, True
+        sub.angles_dev = self.angles_dev[idx].contiguous()
+        sub._angles_host = None if self._angles_host is None else self._angles_host[np.asarray(indices, dtype=np.int64)]
+        sub.n = int(idx.numel())
+        sub._host, sub.G, sub.G_end, sub._post = {}, {}, {}, None
+        sub._pending, sub._force_exact, sub._summary, sub._scalars = False, False, None, None
+        init = None
+        if self._init_host is not None:
+            sel = np.asarray(indices, dtype=np.int64)
+            init = (np.asarray(self._init_host[0])[sel], np.asarray(self._init_host[1])[sel])
+        sub._init_host = init
+        sub._init = (None, None) if self._init[0] is None else (self._init[0][idx], self._init[1][idx])
+        for name in ('n_pts', 'stop_code', 'n_rebounds', 'status', 'monotone', 'slope_max', 'dist', 'step_target', 'T_target'):
+            t = getattr(self, name)
+            setattr(sub, name, None if t is None else t[idx].contiguous())
+        sub.range = self.range[:, idx].contiguous()
+        sub.rebound_cap, sub.total, sub.padded, sub.passes = 0, 0, False, 'subset'
+        sub.tile_off = sub.X = sub.Z = sub.Cpt = None
+        return sub
 
     def _ensure_compact(self):
         """Turns a padded layout (see PADDED_BYTES) into the exact one: X, Z, C and the gains kept so far are copied."""
@@ -708,8 +752,13 @@ class Ray2D:
 
     # lazily materialised arrays --------------------------------------------------------------------
     def _array(self, name, tensor):
+        """tensor: a tile-layout tensor of the fan, or a callable giving it (evaluated once the fan has its trajectories:
+        a subset of a scalars-only fan casts them on first use)."""
         a = self._cache.get(name)
         if a is None:
+            self._fan._need_store()
+            if callable(tensor):
+                tensor = tensor()
             a = self._fan.ray_slice(tensor, self._i).cpu().numpy()
             self._cache[name] = a
         return a
@@ -720,12 +769,12 @@ class Ray2D:
             return np.expand_dims(np.asarray(self.source, dtype=np.float64).copy(), axis=0)
         xz = self._cache.get('XZ')
         if xz is None:
-            xz = np.stack((self._array('X', self._fan.X), self._array('Z', self._fan.Z)), axis=1)
+            xz = np.stack((self._array('X', lambda: self._fan.X), self._array('Z', lambda: self._fan.Z)), axis=1)
             self._cache['XZ'] = xz
         return xz
 
     def _post(self, key):
-        return self._array(key, self._fan.post()[key])
+        return self._array(key, lambda: self._fan.post()[key])
 
     @property
     def dL(self):

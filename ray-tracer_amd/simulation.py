@@ -283,8 +283,9 @@ class EigenraySim2D(Simulation2D):
         kw['n_rebounds_max'] = self.n_rebounds_max
         torch = _torch()
         dist_on = self.distributed and parallel.active()
+        shard_idx = None
         if dist_on:
-            angles, _ = parallel.shard_angles(angles, mode=self.shard)
+            angles, shard_idx = parallel.shard_angles(angles, mode=self.shard)
         sweep = RayFan(self.env, self.source, angles, target=self.target, store=False, **kw)
         self.scan_fan = sweep
         # keep the rays whose distance is among the n_rays smallest distinct distances (simulation.py:241-249):
@@ -292,9 +293,9 @@ class EigenraySim2D(Simulation2D):
         dist = sweep.dist.clone()
         dist[sweep.status != 0] = float('nan')
         if dist_on:
-            # C3: every rank contributes its n_rays best rays, the merged list is the same on every rank (ties beyond a
-            # rank's n_rays-th ray are not kept, unlike the single-process rule below)
-            best_d, best_a = parallel.allgather_topk(dist, sweep.angles_dev, self.n_rays)
+            # C3: every rank contributes the rays within its own n_rays smallest distinct distances; the merged list applies
+            # the single-process rule below to them (ties kept, equal distances in fan order) and is the same on every rank
+            best_d, best_a = parallel.allgather_topk(dist, sweep.angles_dev, self.n_rays, index_local=shard_idx)
             if best_d.numel() == 0:
                 raise KeyError('no scanning ray reaches the target abscissa')
             sel_angles = best_a.cpu().numpy()
@@ -340,10 +341,16 @@ class EigenraySim2D(Simulation2D):
             k = len(prev)
             # note: like the reference (simulation.py:298), refine casts WITHOUT n_rebounds_max
             cones = np.stack([np.linspace(r.angle - cone_half_angle, r.angle + cone_half_angle, n_rays) for r in prev])
-            fan = RayFan(self.env, self.source, cones.reshape(-1), target=self.target, store=True, **self._prop())
+            # Only the distance to the target decides which ray of a cone is kept (simulation.py:272-296), so the cones are
+            # cast WITHOUT trajectories (one pass, per-ray scalars); the winners' trajectories are cast when something
+            # asks for them (RayFan.subset): the kernel is deterministic, the second cast of an angle gives the same ray.
+            # (Without a rebound limit some cone rays run to n_steps_max; storing all of them meant a provisional pass,
+            # then a counting and a storing pass of 100 000 steps each, per iteration.)
+            fan = RayFan(self.env, self.source, cones.reshape(-1), target=self.target, store=False, **self._prop())
             dist = fan.dist.clone()
             dist[fan.status != 0] = float('nan')
             dist = dist.view(k, n_rays).cpu().numpy()
+            picks = []                                            # per parent: -1 = the parent stays, else index into the cone fan
             for ray_id, ray in enumerate(prev):
                 # candidates in the reference's order: the cone rays (duplicate angles skipped), then the parent
                 cand_d, cand = [], []
@@ -361,10 +368,16 @@ class EigenraySim2D(Simulation2D):
                     best = 0                                      # np.sort puts NaN last; dist_sorted[0] is NaN
                 else:
                     best = int(np.nanargmin(cand_d))              # first of the smallest distance
-                if cand[best] == -1:
+                picks.append(-1 if cand[best] == -1 else ray_id * n_rays + cand[best])
+            won = [p for p in picks if p >= 0]
+            winners = fan.subset(won) if won else None            # scalars now, trajectories if and when they are asked for
+            pos = 0
+            for ray, p in zip(prev, picks):                       # the pack in the parents' order, as the reference builds it
+                if p < 0:
                     raypack_refine.add(ray)
                 else:
-                    raypack_refine.add_fan(fan, [ray_id * n_rays + cand[best]])
+                    raypack_refine.add_fan(winners, [pos])
+                    pos += 1
             self._angular_precision /= n_rays
             self.dist_avg = np.mean(raypack_refine.dist_sorted)
             if self.verbose:

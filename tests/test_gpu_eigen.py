@@ -82,3 +82,41 @@ def test_target_products_batched_equals_the_per_ray_loop(rt):
         T_host, _ = ray.gen_filter(target)
         k = int(np.nonzero(a1 == ray.angle)[0][0])
         assert abs(T1[k] - T_host) <= 1e-13 * abs(T_host), (s, T1[k], T_host)
+
+
+@pytest.mark.gpu
+def test_sweep_of_a_million_rays_selects_like_a_host_sort(rt):
+    """BASELINE config 5 at its stated size: n_rays_scan = 1 000 000 over the C2 environment, 1000 rays kept.  The device
+    selection (distinct-distance threshold + stable sort, simulation.py:241-249's rule) against NumPy on the same
+    distances, ties included; then one refine iteration keeps every parent or a ray of its cone that is closer."""
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    target = np.array([40000., -600.])
+    n_scan, n_keep = 1_000_000, 1000
+    sim = rt.EigenraySim2D(env, g['fan_source'], target, n_keep, 20, n_rays_scan=n_scan, scan_angle_min=-0.999,
+                           scan_angle_max=-0.001, dx_max=50., dz_max=25.)
+    assert sim.scan_fan.n == n_scan
+    d = sim.scan_fan.dist.cpu().numpy().copy()
+    d[sim.scan_fan.host('status') != 0] = np.nan
+    angles = np.linspace(-0.999, -0.001, n_scan)
+    kth = np.unique(d[~np.isnan(d)])[n_keep - 1]
+    sel = np.nonzero(d <= kth)[0]
+    sel = sel[np.argsort(d[sel], kind='stable')]
+    got = np.array([r.angle for r in sim.raypacks['scan'].rays])
+    assert len(got) >= n_keep and np.array_equal(got, angles[sel])
+    got_d = np.array([r.dist_to_target for r in sim.raypacks['scan'].rays])
+    assert np.array_equal(got_d, d[sel])                       # the re-cast with trajectories reproduces the sweep's rays
+    # one refine iteration (simulation.py:255-314): every kept ray comes from the cone of a parent (or is the parent), at most
+    # one ray per angle; like the reference, refine casts WITHOUT the rebound limit, so a kept ray may be farther from the
+    # target than its parent was.  The winners carry scalars only until their trajectories are asked for.
+    cone = sim._angular_precision
+    sim.refine(iterations=1, n_rays=5, force_refine=True)
+    pack = sim.raypacks[sim.pack_default]
+    kept = np.array([r.angle for r in pack.rays])
+    assert 0 < len(kept) <= len(got) and len(np.unique(kept)) == len(kept)
+    assert np.all(np.min(np.abs(kept[:, None] - got[None, :]), axis=1) <= cone * (1 + 1e-6) + 1e-15)
+    ray = next(r for r in pack.rays if r._fan.passes == 'subset')
+    d_before = ray.dist_to_target
+    xz = ray.XZ                                                # casts the winners' trajectories now
+    assert xz.shape == (ray.steps, 2) and ray._fan.store and ray._fan.passes == 'count+store'
+    assert float(ray._fan.host('dist')[ray._i]) == d_before    # the second cast of the angle is the same ray

@@ -14,6 +14,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _tie_case():
+    d = np.array([7., 2., 2., 9., 1., 2., np.nan, 1., 3., 3., 2., 8., 1., np.nan, 3., 2.])
+    return d, np.linspace(-0.8, -0.05, len(d))
+
+
 def _worker(rank, world, port, mode, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -43,10 +48,15 @@ def _worker(rank, world, port, mode, out_dir):
     Ht = torch.from_numpy(H)
     parallel.allreduce_heatmap(Ht)                                          # C2
     d = np.array([r.dist_to_target for r in rays])
-    best_d, best_a = parallel.allgather_topk(d, angles, 5)                  # C3
+    best_d, best_a = parallel.allgather_topk(d, angles, 5, index_local=idx)  # C3
+    # ties: a synthetic sweep whose k-th smallest distance is shared by rays on both ranks (and one rank holds more rays
+    # at the smallest distances than k): the merged selection must be the single-process rule's, ties kept, in fan order
+    d_tie, a_tie = _tie_case()
+    a_loc, i_loc = parallel.shard_angles(a_tie, mode=mode)
+    tie_d, tie_a = parallel.allgather_topk(d_tie[i_loc], a_loc, 3, index_local=i_loc)
     if rank == 0:
         np.savez(os.path.join(out_dir, f'{mode}.npz'), H=Ht.numpy().reshape(int(shape[0]), int(shape[1])), lo=lo, hi=hi,
-                 best_d=best_d.numpy(), best_a=best_a.numpy())
+                 best_d=best_d.numpy(), best_a=best_a.numpy(), tie_d=tie_d.numpy(), tie_a=tie_a.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,6 +81,13 @@ def test_two_ranks_reproduce_one(tmp_path, orc, mode):
     order = np.argsort(np.where(np.isnan(d), np.inf, d), kind='stable')[:5]
     assert np.array_equal(got['best_d'], d[order])
     assert np.array_equal(np.sort(got['best_a']), np.sort(g['fan_angles'][order]))
+    # the tie case against the single-process rule (simulation.py:241-249): rays within the 3 smallest distinct distances
+    d_tie, a_tie = _tie_case()
+    kth = np.unique(d_tie[~np.isnan(d_tie)])[2]
+    sel = np.nonzero(d_tie <= kth)[0]
+    sel = sel[np.argsort(d_tie[sel], kind='stable')]
+    assert len(sel) == 11
+    assert np.array_equal(got['tie_d'], d_tie[sel]) and np.array_equal(got['tie_a'], a_tie[sel])
 
 
 def test_shard_angles_cover_the_fan():
