@@ -287,6 +287,22 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
                                 const int32_t* res, const int32_t* shape,
                                 double* H, int64_t* n_dropped, int32_t* work, void* stream);
 
+/* Heat maps of n_freqs frequencies in ONE pass over the trajectories (reference: the frequency loop of populate_NEW,
+ * ray.py:345-362, followed by simulation.py:120-131 once per frequency): the cell of a point and which point of a ray owns
+ * a cell do not depend on the frequency, so they are worked out once and only the deposited value differs per map.
+ * Gs: device array of n_freqs device pointers, each one frequency's gain in tile layout (rt2d_gain).  H: device,
+ * n_freqs maps of nx*nz doubles one after the other, accumulated into (caller zeroes them).  Everything else as for
+ * rt2d_heatmap_accumulate (ray_mask with its hint bits, work, n_dropped: counted once, not per map). */
+int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const double* const* Gs, int32_t n_freqs,
+                                      const int64_t* tile_off, const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                      const int32_t* res, const int32_t* shape,
+                                      double* H, int64_t* n_dropped, int32_t* work, void* stream);
+
+/* rt2d_heatmap_finalize for n_maps maps stored one after the other (H and out), each normalised by its own maximum
+ * (reference: simulation.py:133-138 per map).  scratch: device, at least 2 * n_maps doubles. */
+int32_t rt2d_heatmap_finalize_multi(const double* H, const int32_t* shape, int32_t n_maps, double cutoff,
+                                    double reduction_power, double* out, double* scratch, void* stream);
+
 /* rt2d_heatmap_accumulate for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and same map
  * as rt2d_heatmap_accumulate called with a workspace, but the work list lives in a device array built into the library

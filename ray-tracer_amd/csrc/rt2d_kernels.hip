@@ -157,30 +157,48 @@ __device__ __forceinline__ double rt2d_dpp(double v) {
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-__device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, double val, int lane) {
-    const unsigned long long act = __ballot(want);
-    if (act == 0) return;
-    const int c_prev = __builtin_amdgcn_update_dpp(0, cell, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const bool prev_in = lane > 0 && ((act >> (lane - 1)) & 1ull);
-    const bool head = want && !(prev_in && c_prev == cell);
-    const unsigned long long heads = __ballot(head);
-    const int head_pos = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));    // head of this lane's run
+// The run structure of one deposit (which adjacent depositing lanes share a cell) is computed once and can carry several
+// values: the maps of several frequencies bin the same points into the same cells.
+struct DepositRuns {
+    bool want, tail;
+    int dist, reach, head_pos, lane;
+    __device__ __forceinline__ bool init(bool want_, int cell, int lane_) {
+        want = want_; lane = lane_;
+        const unsigned long long act = __ballot(want);
+        if (act == 0) return false;
+        const int c_prev = __builtin_amdgcn_update_dpp(0, cell, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const bool prev_in = lane > 0 && ((act >> (lane - 1)) & 1ull);
+        const bool head = want && !(prev_in && c_prev == cell);
+        const unsigned long long heads = __ballot(head);
+        head_pos = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));    // head of this lane's run
+        dist = lane - head_pos;
+        reach = want ? min(lane & 15, dist) : -1;
+        tail = want && (lane == RT2D_WAVE - 1 || !((act >> (lane + 1)) & 1ull) || ((heads >> (lane + 1)) & 1ull));
+        return true;
+    }
     // Segmented inclusive scan, all in the vector ALU: four shifts inside each row of 16 lanes, then the two row
     // broadcasts that carry a run across rows.  A lane only adds a value that comes from its own run: `reach` is how
-    // far below itself a lane may look inside its row, -1 for lanes that do not deposit.
-    double v = want ? val : 0.0;
-    const int dist = lane - head_pos;
-    const int reach = want ? min(lane & 15, dist) : -1;
-    { const double u = rt2d_dpp<0x111, 0xf>(v); v += (reach >= 1) ? u : 0.0; }
-    { const double u = rt2d_dpp<0x112, 0xf>(v); v += (reach >= 2) ? u : 0.0; }
-    { const double u = rt2d_dpp<0x114, 0xf>(v); v += (reach >= 4) ? u : 0.0; }
-    { const double u = rt2d_dpp<0x118, 0xf>(v); v += (reach >= 8) ? u : 0.0; }
-    { const double u = rt2d_dpp<0x142, 0xa>(v);                                  // rows 1 and 3 <- lane 15 / 47
-      v += (want && (lane & 16) && dist > (lane & 15)) ? u : 0.0; }
-    { const double u = rt2d_dpp<0x143, 0xc>(v);                                  // rows 2 and 3 <- lane 31
-      v += (want && lane >= 32 && head_pos <= 31) ? u : 0.0; }
-    const bool tail = want && (lane == RT2D_WAVE - 1 || !((act >> (lane + 1)) & 1ull) || ((heads >> (lane + 1)) & 1ull));
-    if (tail) atomicAdd(&H[cell], v);
+    // far below itself a lane may look inside its row, -1 for lanes that do not deposit.  The last lane of a run holds
+    // the run's sum.
+    __device__ __forceinline__ double sum(double val) const {
+        double v = want ? val : 0.0;
+        { const double u = rt2d_dpp<0x111, 0xf>(v); v += (reach >= 1) ? u : 0.0; }
+        { const double u = rt2d_dpp<0x112, 0xf>(v); v += (reach >= 2) ? u : 0.0; }
+        { const double u = rt2d_dpp<0x114, 0xf>(v); v += (reach >= 4) ? u : 0.0; }
+        { const double u = rt2d_dpp<0x118, 0xf>(v); v += (reach >= 8) ? u : 0.0; }
+        { const double u = rt2d_dpp<0x142, 0xa>(v);                                  // rows 1 and 3 <- lane 15 / 47
+          v += (want && (lane & 16) && dist > (lane & 15)) ? u : 0.0; }
+        { const double u = rt2d_dpp<0x143, 0xc>(v);                                  // rows 2 and 3 <- lane 31
+          v += (want && lane >= 32 && head_pos <= 31) ? u : 0.0; }
+        return v;
+    }
+};
+
+__device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, double val, int lane) {
+    DepositRuns runs;
+    if (!runs.init(want, cell, lane)) return;
+    const double v = runs.sum(val);
+    if (runs.tail) atomicAdd(&H[cell], v);
 }
 
 // "Last write wins" for a ray whose heat-map column never decreases and whose points all fall inside the map, fed
@@ -1413,6 +1431,8 @@ struct HeatArgs {
     double* H; int64_t* n_dropped; int32_t cap;     // cap: hash slots per ray, power of two
     int32_t cell_cap;                               // points per ray whose cells are cached in LDS
     int32_t split;                                  // tile kernel: waves per tile, each walking a range of rows
+    // several frequencies at once (rt2d_heatmap_accumulate_multi): map f is H + f * map_stride, its gains Gs[f]
+    const double* const* Gs; int32_t n_freqs; int64_t map_stride;
 };
 
 // Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
@@ -1424,8 +1444,21 @@ struct HeatArgs {
 #ifndef HM_UNROLL
 #define HM_UNROLL 4      // measured: 8 rows in flight cost registers and 1.7 ms per 1M rays
 #endif
-template <int MW>     // 64-bit mask words per lane: rows nz <= 64 * MW
+template <int MW, int FB>     // MW: 64-bit mask words per lane (rows nz <= 64 * MW); FB: maps (frequencies) binned per pass
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
+    // FB > 1: blockIdx.y picks a group of FB frequencies.  The cells of a point, "first time this (column, row) is seen" and
+    // the runs of equal cells across the wave are the same for every frequency: they are worked out once per point and
+    // only the value (2^x of that frequency's gain) and the run sums are per frequency.
+    const int f0 = (FB > 1) ? (int)blockIdx.y * FB : 0;
+    const double* Gk[FB];
+    double* Hk[FB];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+        const int f = (FB > 1) ? min(f0 + k, a.n_freqs - 1) : 0;      // a group past the end repeats the last map's gains ...
+        Gk[k] = (FB > 1) ? a.Gs[f] : a.G;
+        Hk[k] = a.H + (int64_t)f * a.map_stride;
+    }
+    const int nf = (FB > 1) ? min(FB, a.n_freqs - f0) : 1;            // ... but only deposits the first nf
     // Fans of 10^4..10^5 rays have too few tiles to give a SIMD more than one wave, and then the kernel's time is the
     // length of one wave's walk.  Such a tile is walked by `split` waves, each taking a contiguous range of ROWS (see
     // "rows of this wave" below); tiles with unchecked rays are walked whole by their first wave.
@@ -1485,18 +1518,14 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     // kernel's lines are shared by neighbouring rays, see its item mapping)
     const bool queued = send ? seg == 0 : (!ok && !hinted);
     const unsigned long long qmask = __ballot(queued);
-    if (qmask) {
+    if (qmask && (FB == 1 || blockIdx.y == 0)) {
         const int leader = __ffsll((long long)qmask) - 1;
         int k0 = 0;
         if (lane == leader) k0 = atomicAdd(&a.work[0], __popcll(qmask));
         k0 = __shfl(k0, leader);
-        if (queued) {
-            a.work[2 + k0 + __popcll(qmask & ((1ull << lane) - 1ull))] = (int32_t)r;
-            np = 0;
-            last = 0;
-        }
+        if (queued) a.work[2 + k0 + __popcll(qmask & ((1ull << lane) - 1ull))] = (int32_t)r;
     }
-    if (send) { np = 0; last = 0; }
+    if (queued | send) { np = 0; last = 0; }
     tmax = np;
     for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, __shfl_xor(tmax, off));
 
@@ -1538,22 +1567,22 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
         }
     }
     for (int s0 = row_hi - 1; s0 >= row_lo; s0 -= HM_UNROLL) {
-        double xs[HM_UNROLL], zs[HM_UNROLL], gs[HM_UNROLL];
+        double xs[HM_UNROLL], zs[HM_UNROLL], gs[HM_UNROLL][FB];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
             const int64_t o = base + (int64_t)min(max(s0 - u, 0), last) * RT2D_WAVE;
             xs[u] = a.X[o];
             zs[u] = a.Z[o];
-            gs[u] = a.G[o];
+#pragma unroll
+            for (int k = 0; k < FB; ++k) gs[u][k] = Gk[k][o];
         }
-        unsigned late = 0u;                                 // rows of this batch whose value needs the two pows
+        unsigned late = 0u;                                 // (row, map) pairs of this batch whose value needs the two pows
         int late_cell[HM_UNROLL];
 #pragma unroll
         for (int u = 0; u < HM_UNROLL; ++u) {
             const int s = s0 - u;
             bool fresh = false;
             int cell = -1 - lane;                           // unique per lane: never merges
-            double val = 0.0;
             late_cell[u] = 0;
             if (s >= row_lo && s < np) {
                 int ix, iz;
@@ -1567,26 +1596,38 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
                 const int word = iz >> 6;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) if (w == word) { fresh = (seen[w] & bit) == 0; seen[w] |= bit; }
-                if (fresh) {
-                    cell = ix * nz + iz;
-                    if (__builtin_expect(rt2d_heat_val_is_plain(gs[u]), 1)) val = rt2d_heat_val_plain(gs[u]);   // ray.py:317, simulation.py:129
-                    else if (rt2d_heat_val_is_inf(gs[u])) val = rt2d_heat_val_of_inf(gs[u]);
-                    else { fresh = false; late |= 1u << u; late_cell[u] = cell; }
-                }
+                if (fresh) { cell = ix * nz + iz; late_cell[u] = cell; }
             }
             // Neighbouring lanes are neighbouring angles: at one step they mostly sit in the same cell.  Runs of
-            // equal cells across the wave are summed and the last lane of each run issues ONE atomic.
-            rt2d_deposit(a.H, fresh, cell, val, lane);
+            // equal cells across the wave are summed and the last lane of each run issues ONE atomic per map.
+            DepositRuns runs;
+            if (!runs.init(fresh, cell, lane)) continue;
+#pragma unroll
+            for (int k = 0; k < FB; ++k) {
+                if (k >= nf) break;
+                double val = 0.0;
+                if (fresh) {
+                    const double g = gs[u][k];
+                    if (__builtin_expect(rt2d_heat_val_is_plain(g), 1)) val = rt2d_heat_val_plain(g);   // ray.py:317, simulation.py:129
+                    else if (rt2d_heat_val_is_inf(g)) val = rt2d_heat_val_of_inf(g);
+                    else late |= 1u << (u * FB + k);        // adds 0 to its run here, the real value below
+                }
+                const double v = runs.sum(val);
+                if (runs.tail) atomicAdd(&Hk[k][cell], v);
+            }
         }
         // gains beyond +-3000 dB (a surface coefficient that underflowed to 0 at high frequency): the pow pair of the
         // reference, kept out of the loop above and present once in the program
         while (__builtin_expect(late != 0u, 0)) {
-            const int u = __ffs(late) - 1;
+            const int b = __ffs(late) - 1;
             late &= late - 1u;
-            double g = gs[0]; int cell = late_cell[0];
+            const int u = b / FB, k = b % FB;
+            double g = gs[0][0]; int cell = late_cell[0]; double* Hm = Hk[0];
 #pragma unroll
-            for (int k = 1; k < HM_UNROLL; ++k) if (u == k) { g = gs[k]; cell = late_cell[k]; }
-            atomicAdd(&a.H[cell], rt2d_heat_val_pows(g));
+            for (int uu = 0; uu < HM_UNROLL; ++uu)
+#pragma unroll
+                for (int kk = 0; kk < FB; ++kk) if (u == uu && k == kk) { g = gs[uu][kk]; cell = late_cell[uu]; Hm = Hk[kk]; }
+            atomicAdd(&Hm[cell], rt2d_heat_val_pows(g));
         }
     }
 }
@@ -1684,11 +1725,12 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
             // pass B: the step that owns its cell deposits (simulation.py:129-131); up to eight points per lane at a time so
             // that their gain loads travel together
             for (int s0 = 0; s0 < np; s0 += 8 * HM_THREADS) {
-                int32_t own[8]; double gv[8];
+                int32_t own[8]; double gv[8]; int own_s[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int sx = s0 + u * HM_THREADS + lane;
                     own[u] = -1;
+                    own_s[u] = sx;
                     gv[u] = 0.0;
                     if (sx >= np) continue;
                     const int32_t cell = cell_at(sx);
@@ -1701,15 +1743,26 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                         const unsigned long long cur = s_hash[slot];
                         if (cur == HM_EMPTY) break;
                         if ((cur >> 32) == (unsigned long long)(uint32_t)cell) {
-                            if ((uint32_t)cur == (uint32_t)sx) { own[u] = cell; gv[u] = a.G[base + (int64_t)sx * RT2D_WAVE]; }
+                            if ((uint32_t)cur == (uint32_t)sx) { own[u] = cell; if (a.n_freqs == 0) gv[u] = a.G[base + (int64_t)sx * RT2D_WAVE]; }
                             break;
                         }
                         slot = (slot + 1) & mask;
                     }
                 }
+                if (a.n_freqs == 0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (own[u] >= 0) atomicAdd(&a.H[own[u]], rt2d_heat_val(gv[u]));     // ray.py:317, simulation.py:129
+                    for (int u = 0; u < 8; ++u)
+                        if (own[u] >= 0) atomicAdd(&a.H[own[u]], rt2d_heat_val(gv[u]));     // ray.py:317, simulation.py:129
+                } else {
+                    // several maps: the owning step of a cell is the same for every frequency, only the value differs
+                    for (int f = 0; f < a.n_freqs; ++f) {
+                        const double* Gf = a.Gs[f];
+                        double* Hf = a.H + (int64_t)f * a.map_stride;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (own[u] >= 0) atomicAdd(&Hf[own[u]], rt2d_heat_val(Gf[base + (int64_t)own_s[u] * RT2D_WAVE]));
+                    }
+                }
             }
             __syncthreads();
         }
@@ -1729,7 +1782,8 @@ __device__ __forceinline__ double rt2d_order_value(unsigned long long k) {
 }
 
 __global__ void rt2d_hm_max_kernel(const double* H, int64_t size, unsigned long long* scratch) {
-    // scratch[0]: order key of the maximum (0 = nothing seen yet); scratch[1]: NaN flag
+    // scratch[0]: order key of the maximum (0 = nothing seen yet); scratch[1]: NaN flag; blockIdx.y: map of a batch
+    H += (int64_t)blockIdx.y * size; scratch += 2 * blockIdx.y;
     double m = -INFINITY; bool nan = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += (int64_t)gridDim.x * blockDim.x) {
         double v = H[i];
@@ -1747,6 +1801,7 @@ __global__ void rt2d_hm_finalize_kernel(const double* H, int64_t nx, int64_t nz,
                                         const unsigned long long* scratch, double* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nx * nz) return;
+    H += (int64_t)blockIdx.y * nx * nz; out += (int64_t)blockIdx.y * nx * nz; scratch += 2 * blockIdx.y;
     double mx = scratch[1] ? __builtin_nan("") : rt2d_order_value(scratch[0]);
     int64_t ix = i / nz, iz = i % nz;
     double v = H[i] / mx;
@@ -2288,7 +2343,8 @@ extern "C++" {
 static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                        const int32_t* res, const int32_t* shape,
-                                       double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream);
+                                       double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
+                                       const double* const* Gs = nullptr, int32_t n_freqs = 0);
 }
 
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
@@ -2302,8 +2358,9 @@ extern "C++" {
 static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                        const int32_t* res, const int32_t* shape,
-                                       double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream) {
-    if (!X || !Z || !G || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
+                                       double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
+                                       const double* const* Gs, int32_t n_freqs) {
+    if (!X || !Z || (!G && !Gs) || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
     if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
     if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
     if (shape[0] <= 0 || shape[1] <= 0 || (int64_t)shape[0] * shape[1] >= (1ll << 31)) return fail("rt2d_heatmap_accumulate: bad shape");
@@ -2311,6 +2368,8 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     HeatArgs a; memset(&a, 0, sizeof a);
     a.X = X; a.Z = Z; a.G = G; a.tile_off = tile_off; a.n_pts = n_pts; a.n = n;
     a.ray_mask = ray_mask;
+    a.Gs = Gs; a.n_freqs = Gs ? n_freqs : 0; a.map_stride = (int64_t)shape[0] * shape[1];
+    n_freqs = a.n_freqs;
     a.geo.res_x = res[0]; a.geo.res_z = res[1]; a.geo.rx = res[0]; a.geo.rz = res[1];
     a.geo.inv_rx = 1.0 / res[0]; a.geo.inv_rz = 1.0 / res[1];
     a.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
@@ -2339,8 +2398,12 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         static const int wpb_env = getenv("RT2D_HM_WPB") ? atoi(getenv("RT2D_HM_WPB")) : 0;
         const int wpb = wpb_env > 0 ? wpb_env : ((n_waves <= 1024) ? 1 : 4);
         const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
-        if (shape[1] <= 64) hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<1>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
-        else hipLaunchKernelGGL(rt2d_heatmap_fast_kernel<4>, dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        if (n_freqs > 0) {
+            const unsigned groups = (unsigned)((n_freqs + 3) / 4);
+            if (shape[1] <= 64) hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<1, 4>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
+            else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 4>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        } else if (shape[1] <= 64) hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<1, 1>), dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 1>), dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
         HIP_OK(hipGetLastError());
     }
     // general kernel: everything (no workspace) or what the fast kernel queued; blocks stride over the items
@@ -2392,6 +2455,33 @@ int32_t rt2d_heatmap_accumulate_noalloc(const double* X, const double* Z, const 
     // the implementation zeroes the two header words of the list (hipMemsetAsync on `stream`) before the tile kernel fills
     // it: nothing of the previous call's contents is read
     return heatmap_accumulate_impl(X, Z, G, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream);
+}
+
+int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const double* const* Gs, int32_t n_freqs,
+                                      const int64_t* tile_off, const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                      const int32_t* res, const int32_t* shape,
+                                      double* H, int64_t* n_dropped, int32_t* work, void* stream) {
+    if (!Gs) return fail("rt2d_heatmap_accumulate_multi: null argument");
+    if (n_freqs <= 0) return n_freqs == 0 ? 0 : fail("rt2d_heatmap_accumulate_multi: negative frequency count");
+    return heatmap_accumulate_impl(X, Z, nullptr, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream, Gs, n_freqs);
+}
+
+int32_t rt2d_heatmap_finalize_multi(const double* H, const int32_t* shape, int32_t n_maps, double cutoff, double reduction_power,
+                                    double* out, double* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!H || !shape || !out || !scratch) return fail("rt2d_heatmap_finalize_multi: null argument");
+    const int64_t nx = shape[0], nz = shape[1], size = nx * nz;
+    if (nx <= 0 || nz <= 0) return fail("rt2d_heatmap_finalize_multi: bad shape");
+    if (n_maps <= 0) return n_maps == 0 ? 0 : fail("rt2d_heatmap_finalize_multi: negative map count");
+    HIP_OK(hipMemsetAsync(scratch, 0, (size_t)n_maps * 2 * sizeof(double), stream));
+    const int block = 256;
+    const int64_t blocks = (size + block - 1) / block;
+    hipLaunchKernelGGL(rt2d_hm_max_kernel, dim3((unsigned)(blocks < 128 ? blocks : 128), (unsigned)n_maps), dim3(block), 0, stream,
+                       H, size, (unsigned long long*)scratch);
+    hipLaunchKernelGGL(rt2d_hm_finalize_kernel, dim3((unsigned)blocks, (unsigned)n_maps), dim3(block), 0, stream,
+                       H, nx, nz, cutoff, reduction_power, (const unsigned long long*)scratch, out);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cutoff, double reduction_power,

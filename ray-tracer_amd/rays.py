@@ -621,6 +621,27 @@ class RayFan:
             self.last_slow_rays = n_rest
             self.last_fused_violations = viol
 
+    def heatmap_accumulate_multi(self, H, res, shape, freqs, ray_mask=None, dropped=None):
+        """Adds this fan's rays into the maps of several frequencies at once (H: (F, nx*nz) device f64, contiguous): one
+        pass over the trajectories for all of them (rt2d_heatmap_accumulate_multi)."""
+        self._need_store()
+        torch = _torch()
+        L = _lib.lib()
+        freqs = list(freqs)
+        self.populate(*freqs)
+        with torch.cuda.device(self.device):
+            res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
+            shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+            work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device)
+            if self.n > HEATMAP_FAST_MIN_RAYS:
+                ray_mask = self.heatmap_mask(res, shape, ray_mask)
+            ptrs = torch.tensor([self.G[f].data_ptr() for f in freqs], dtype=torch.int64, device=self.device)
+            _lib.check(L.rt2d_heatmap_accumulate_multi(self.X.data_ptr(), self.Z.data_ptr(), ptrs.data_ptr(), len(freqs),
+                                                       self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, _ptr(ray_mask),
+                                                       res_c, shape_c, H.data_ptr(), _ptr(dropped), work.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream))
+            self._last_slow = work
+
     @property
     def last_slow_rays(self):
         """Rays of the last heatmap_accumulate* call that went through the general (one workgroup per ray) kernel."""

@@ -207,14 +207,50 @@ class Simulation2D:
 
     def heatmaps(self, freqs, **kwargs):
         """One heat map per frequency (BASELINE config 4: an array of frequencies, frequency-dependent rebound loss).
-        The gains of all frequencies are populated by ONE launch (eight frequencies per lane share the six absorption
-        table look-ups of a point), then each map is binned and normalised as ``heatmap(freq=f)`` does.
-        Returns {freq: (nz, nx) array}."""
+        The gains of all frequencies come from ONE launch (eight frequencies per lane share the six absorption table
+        look-ups of a point), all maps are binned in ONE pass over the trajectories (the cell of a point does not depend
+        on the frequency: rt2d_heatmap_accumulate_multi), normalised by one launch and copied back once.
+        ``batched=False``: one ``heatmap(freq=f)`` per frequency instead.  Returns {freq: (nz, nx) array}."""
+        torch = _torch()
         freqs = list(freqs)
         pack = self.raypacks[kwargs.get('pack', self.pack_default)]
-        if all(fan.store for fan, _ in pack.segments()):
-            pack.populate(*freqs)
-        return {f: self.heatmap(freq=f, **kwargs) for f in freqs}
+        segs = pack.segments()
+        dist_on = getattr(pack, 'sharded', False) and parallel.active()
+        if not kwargs.get('batched', True) or not segs or not all(fan.store for fan, _ in segs) or not freqs:
+            if all(fan.store for fan, _ in segs):
+                pack.populate(*freqs)
+            return {f: self.heatmap(freq=f, **kwargs) for f in freqs}
+        res = self._resolution(kwargs)
+        device = segs[0][0].device
+        if dist_on:
+            lo, hi = parallel.allreduce_plot_range(pack.range_min_plot, pack.range_max_plot, device=device)
+            shape = parallel.heatmap_shape(lo, hi, res)
+        else:
+            shape = np.ceil(pack.size_plot / res).astype(int) + 1
+        nx, nz, F = int(shape[0]), int(shape[1]), len(freqs)
+        with torch.cuda.device(device):
+            H = torch.zeros((F, nx * nz), dtype=torch.float64, device=device)
+            for fan, idx in segs:
+                mask = None
+                if len(idx) != fan.n:
+                    mask = torch.zeros(fan.n, dtype=torch.uint8, device=device)
+                    mask[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=device)] = 1
+                fan.heatmap_accumulate_multi(H, res, shape, freqs, ray_mask=mask)
+            if dist_on:
+                parallel.allreduce_heatmap(H)
+            out = torch.empty((F, nz, nx), dtype=torch.float64, device=device)
+            scratch = torch.empty(2 * F, dtype=torch.float64, device=device)
+            _lib.check(_lib.lib().rt2d_heatmap_finalize_multi(H.data_ptr(), (C.c_int32 * 2)(nx, nz), F, float(kwargs.get('cutoff', .02)),
+                                                              float(kwargs.get('reduction_power', .5)), out.data_ptr(),
+                                                              scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        if kwargs.get('as_tensor', False):
+            return {f: out[k] for k, f in enumerate(freqs)}
+        # one copy of all maps through page-locked memory (38 MB for 64 maps of 1500 x 51: 10 ms pageable, 2 ms pinned)
+        pinned = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        pinned.copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = pinned.numpy()                     # (the arrays keep the page-locked buffer alive)
+        return {f: host[k] for k, f in enumerate(freqs)}
 
     def plot_heatmap(self, ax=None, floor=True, **kwargs):
         """heatmap(**kwargs) drawn with metre ticks and the sea floor painted over it (deprecated.ipynb cell 4)."""

@@ -279,12 +279,17 @@ def test_heatmaps_for_an_array_of_frequencies(rt, orc):
     oenv = common.oracle_env_from_product(orc, env)
     sim = rt.Simulation2D(env, g['fan_source'])
     fan = sim.cast(g['fan_angles'], **common.prop_kwargs(g))
-    freqs = [float(f) for f in g['fan_freqs'][[0, 5, 21, 63]]]
+    freqs = [float(f) for f in g['fan_freqs']]                 # all 64, binned in one pass over the trajectories
     maps = sim.heatmaps(freqs, resolution=[50, 25], cutoff=.1)
-    assert set(fan.G) >= set(freqs)
+    assert set(fan.G) >= set(freqs) and len(maps) == 64
     rays = [r for r in _oracle_rays_from_fan(orc, rt, fan) if r.status == 0]
     for r in rays:
         _oracle_post(orc, oenv, r)
+    one_by_one = sim.heatmaps(freqs[::9], resolution=[50, 25], cutoff=.1, batched=False)
+    for f, m in one_by_one.items():
+        fin = np.isfinite(m)
+        assert np.array_equal(np.isfinite(maps[f]), fin) and np.abs(maps[f] - m)[fin].max(initial=0) < 1e-12
+    freqs = [freqs[k] for k in (0, 5, 21, 63)]
     for f in freqs:
         _, plot_ref, _ = orc.heatmap(oenv, rays, res=(50, 25), cutoff=.1, freq=f)
         assert maps[f].shape == plot_ref.shape
@@ -370,3 +375,21 @@ def test_populate_after_keep_arrays_false(rt):
     H = torch.zeros(1100 * 45, dtype=torch.float64, device='cuda')
     fan.heatmap_accumulate(H, (50, 25), (1100, 45), freq=1000.)
     assert 1000. in fan.G and float(H.sum().item()) > 0
+
+
+def test_multi_frequency_binning_on_a_large_fan(rt):
+    """20 000 rays (tile kernel for the forward rays, general kernel for the turned-back ones), 6 frequencies -- not a
+    multiple of the 4 maps a pass bins -- in one pass against one heat map per frequency: every cell to 1e-12."""
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    sim = rt.Simulation2D(env, g['fan_source'])
+    fan = sim.cast(-(np.arange(20000) + 1) * (0.999 / 20000), **common.prop_kwargs(g))
+    freqs = [1., 40., 300., 1000., 5000., 20000.]
+    both = sim.heatmaps(freqs, resolution=[50, 25], cutoff=.5)
+    assert fan.last_slow_rays > 0
+    for f in freqs:
+        one = sim.heatmap(freq=f, resolution=[50, 25], cutoff=.5)
+        assert one.shape == both[f].shape
+        fin = np.isfinite(one)
+        assert np.array_equal(np.isfinite(both[f]), fin) and not np.isnan(both[f][fin]).any()
+        assert np.abs(both[f] - one)[fin].max() < 1e-12
