@@ -451,6 +451,9 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 
 // Development aid: when a log buffer is set (rt2d_debug_wave_log), every wave records when it started and ended (100 MHz
 // clock) and where it ran; the destructor runs wherever the lane of the wave's first thread leaves the kernel.
+#ifndef RT2D_WAVE_LOG
+struct WaveLog { __device__ __forceinline__ WaveLog(const CastArgs&) {} };     // compiled out (costs four registers): -DRT2D_WAVE_LOG
+#else
 struct WaveLog {
     unsigned long long* slot; unsigned long long t0;
     __device__ __forceinline__ WaveLog(const CastArgs& a) : slot(nullptr), t0(0) {
@@ -467,6 +470,7 @@ struct WaveLog {
         slot[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));         // XCC_ID
     }
 };
+#endif
 
 // WRITE: store the trajectory.  TAB: where the step tables are read from (see the kernel).
 // POST: 0 = counts only (the counting pass of a stored cast); 1 = + bounding box of the ray (what the heat-map
@@ -606,7 +610,83 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         return (int)vmin(vmax(g, 0.0), jmax);                               // NaN -> 0 through the max
     };
 
-    for (int i = 0; i < p.n_steps_max; ++i) {
+    // Plain steps: a step of dx_max (ray not steep) whose point is inside the rectangle, between floor and surface, with
+    // all table guesses right and room left in its tile -- nothing but the curvature update happens.  While EVERY ray of
+    // the wave takes such a step the wave stays in the tight loop below: the same statements as the common path of the
+    // general step further down (same order, same roundings: the trajectories are bit for bit the same), but with ONE
+    // wave-uniform exit, so that none of the per-lane exit bookkeeping of the general loop (ended rays, rebounds, clipped
+    // points, the choice of the division) is carried through it.  The step that the wave cannot take together is left
+    // untouched for the general loop, which then tries the tight loop again.  (The waves of a small fan hold four shallow
+    // rays that rebound twenty times in 1500 steps: they spend nine steps in ten here.)
+    constexpr bool TIGHT = (POST <= 1) && !CUTOFF && (FUSE == 0);
+    const bool tight_on = TIGHT && !(WRITE && a.C != nullptr);
+    int i = 0;
+    int tight_wait = 0, tight_penalty = 1;      // wave-uniform: steps until the tight loop is tried again, doubled by every
+                                                // attempt that takes no step (a wave of steep rays rebounds somewhere in
+                                                // almost every step and would pay for the attempt each time)
+    for (; i < p.n_steps_max; ++i) {
+        if (tight_on && tight_wait > 0) --tight_wait;
+        else if (tight_on) {
+            const int i_in = i;
+            while (i < p.n_steps_max - 1) {
+                const double kx_s = kx * p.dx_max, kz_s = kz * p.dx_max;          // ray.py:154 (not steep)
+                const double xn = x + kx_s, zn = z + kz_s;                         // ray.py:157
+                const double xa_t = vmin(vmax(xn, fl_lo), fl_hi);
+                const double xb_t = CEILC ? 0.0 : vmin(vmax(xn, ce_lo), ce_hi);
+                const int ja_t = guess(e.floor, xa_t, fl_jmax), jb_t = CEILC ? 0 : guess(e.ceil, xb_t, ce_jmax);
+                const int jz_t = guess(e.cz, zn, cz_jmax);
+                double ta[4], tb[4], tz8[8];
+                {
+                    auto pa = tab_fl + e.floor.off + ja_t * 3;
+                    auto pzr = tab_cz + e.cz.off + jz_t * 7;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ta[k] = pa[k];
+                    if (!CEILC) {
+                        auto pb = tab_fl + e.ceil.off + jb_t * 3;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) tb[k] = pb[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) tz8[k] = pzr[k];
+                }
+                // (every word of the three records is wanted HERE: without this the compiler sinks the loads of the
+                // coefficients behind the exit test below, a second LDS round trip on the critical path of every step)
+                asm volatile("" :: "v"(ta[1]), "v"(ta[2]), "v"(tz8[1]), "v"(tz8[2]), "v"(tz8[3]), "v"(tz8[4]), "v"(tz8[5]), "v"(tz8[6]));
+                // the guessed pieces must be the right ones WITHOUT the end-piece exceptions of the general step (a point in
+                // an end piece that fails here is simply left to the general step)
+                const bool in_a = (xa_t >= ta[0]) & (xa_t < ta[3]) & (e.floor.uniform != 0);
+                const bool in_b = CEILC ? true : ((xb_t >= tb[0]) & (xb_t < tb[3]) & (e.ceil.uniform != 0));
+                const bool in_z = (zn >= tz8[0]) & (zn < tz8[7]) & (e.cz.uniform != 0);
+                const double zf_t = ta[1] * (xa_t - ta[0]) + ta[2];
+                const double zc_t = CEILC ? a.ceil_const : tb[1] * (xb_t - tb[0]) + tb[2];
+                const bool inside = (xn >= e.range_min[0]) & (xn <= e.range_max[0]) & (zn >= vmax(z_lo_bound, zf_t))
+                                  & (zn <= (CEILC ? z_hi_bound : vmin(z_hi_bound, zc_t)));
+                const bool plain_t = !(fabs(dx_z) > dx_z_max) & in_a & in_b & in_z & inside
+                                   & (fabs(kx_s) == p.dx_max) & (fabs(kz_s) >= 1e-250) & (!WRITE | (n_pts < room));
+                if (!rt2d_all(plain_t)) break;
+                // commit (ray.py:235-247)
+                if (POST >= 1) { slope_max = vmax(slope_max, fabs(dx_z)); mono &= !(xn < x); }
+                x = xn; z = zn;
+                const double dzr_t = z - tz8[0];
+                c = rt2d_quad_of(tz8, dzr_t, 0);
+                const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
+                if (POST >= 1) {
+                    min_x = vmin(min_x, x); max_x = vmax(max_x, x);
+                    min_z = vmin(min_z, z); max_z = vmax(max_z, z);
+                }
+                if (WRITE) { px += RT2D_WAVE; pz += RT2D_WAVE; *px = x; *pz = z; }
+                n_pts += 1;
+                x_dir = rt2d_sign(kx_s);
+                const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);      // k1/k0 (ray.py:243)
+                dx_z = (kx_s < 0.0) ? -1 * q_t : q_t;
+                const double dxdx_t = mult * dz_c_t / (c * c * c);
+                dx_z += dxdx_t * kx_s;
+                kx = x_dir; kz = dx_z;
+                ++i;
+            }
+            if (i == i_in) { tight_wait = tight_penalty; tight_penalty = min(2 * tight_penalty, 64); }
+            else tight_penalty = 1;
+        }
         // step sizing (ray.py:153-154)
         const bool steep = fabs(dx_z) > dx_z_max;
         if (POST >= 1) slope_max = vmax(slope_max, fabs(dx_z));
