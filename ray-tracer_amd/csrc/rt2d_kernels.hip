@@ -201,6 +201,27 @@ __device__ __forceinline__ void rt2d_deposit(double* H, bool want, int cell, dou
     if (runs.tail) atomicAdd(&H[cell], v);
 }
 
+// The same for callers whose wave runs with ALL 64 lanes enabled (lanes without a deposit pass want = false): when every
+// depositing lane holds the same cell -- neighbouring rays of a sorted fan, most steps -- the run bookkeeping drops
+// out and the wave's sum is one unconditional scan (18 instructions instead of ~55); lane 63 issues the atomic.
+__device__ __forceinline__ void rt2d_deposit_full(double* H, bool want, int cell, double val, int lane) {
+    const unsigned long long wm = __builtin_amdgcn_ballot_w64(want);
+    if (wm == 0ull) return;
+    const int c0 = __builtin_amdgcn_readlane(cell, (int)__builtin_ctzll(wm));
+    if (__builtin_amdgcn_ballot_w64(want & (cell == c0)) == wm) {
+        double v = want ? val : 0.0;
+        v += rt2d_dpp<0x111, 0xf>(v);
+        v += rt2d_dpp<0x112, 0xf>(v);
+        v += rt2d_dpp<0x114, 0xf>(v);
+        v += rt2d_dpp<0x118, 0xf>(v);                 // lane 15 of each row: the row's sum
+        v += rt2d_dpp<0x142, 0xa>(v);                 // lanes 31 and 63: two rows (rows 0 and 2 hold nothing of use from here on)
+        v += rt2d_dpp<0x143, 0xc>(v);                 // lane 63: the wave
+        if (lane == RT2D_WAVE - 1) atomicAdd(&H[c0], v);
+        return;
+    }
+    rt2d_deposit(H, want, cell, val, lane);
+}
+
 // "Last write wins" for a ray whose heat-map column never decreases and whose points all fall inside the map, fed
 // point by point in path order (functions.py:16 semantics without storing the ray).  Such a ray can only come back to a
 // cell while it is still in the same column, so the memory it needs is local to that column: 8 slots per lane
@@ -220,6 +241,8 @@ struct RayBinner {
     double* slot;
 
     // deposits the cell this lane is leaving (want); stay: the ray stays in the column, so the row must be remembered
+    // FULL: the caller's wave has all 64 lanes enabled (rt2d_deposit_full)
+    template <bool FULL = false>
     __device__ __forceinline__ void leave(const BinTarget& t, bool want, bool stay, int lane) {
         if (t.dbg & 2) return;
         double v = 0.0, prev = 0.0;
@@ -234,6 +257,7 @@ struct RayBinner {
         // gives v = prev = +inf on a row the ray comes back to, and the cell already holds the +inf the reference puts there
         const double d = (v == prev) ? 0.0 : v - prev;
         if (t.dbg & 1) { if (want) atomicAdd(&t.H[cell], d); }
+        else if (FULL) rt2d_deposit_full(t.H, want, cell, d, lane);
         else rt2d_deposit(t.H, want, cell, d, lane);
     }
     // first point of the ray (gain g)
@@ -246,22 +270,25 @@ struct RayBinner {
         } else { ok = false; violated = true; }
     }
     // next point of the ray; callable from divergent code (the deposit only involves the calling lanes)
-    __device__ __forceinline__ void point(const BinTarget& t, double x, double z, double g, int lane) {
+    // (live = false: the lane has no point this time and only takes part in the wave's deposit)
+    template <bool FULL = false>
+    __device__ __forceinline__ void point(const BinTarget& t, double x, double z, double g, int lane, bool live = true) {
         int ix, iz;
         const bool in_map = rt2d_cell_i32(t.geo, x, z, ix, iz) && (unsigned)ix < (unsigned)t.nx && (unsigned)iz < (unsigned)t.nz;
-        if (ok && (!in_map || ix < cur_ix)) { ok = false; violated = true; }
-        const bool newcol = ok && ix != cur_ix;
-        const bool newrow = ok && !newcol && iz != cur_iz;
-        leave(t, newcol | newrow, newrow, lane);
+        if (live && ok && (!in_map || ix < cur_ix)) { ok = false; violated = true; }
+        const bool newcol = live && ok && ix != cur_ix;
+        const bool newrow = live && ok && !newcol && iz != cur_iz;
+        leave<FULL>(t, newcol | newrow, newrow, lane);
         if (newcol) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; occ = 0u; }
         else if (newrow) {
             cur_iz = iz; col_lo = min(col_lo, iz); col_hi = max(col_hi, iz);
             if (col_hi - col_lo >= 8) { ok = false; violated = true; }      // two rows would share a slot
         }
-        if (ok) cur_g = g;
+        if (live && ok) cur_g = g;
     }
     // after the last point: the cell the ray ends in
-    __device__ __forceinline__ void finish(const BinTarget& t, int lane) { leave(t, ok, false, lane); }
+    template <bool FULL = false>
+    __device__ __forceinline__ void finish(const BinTarget& t, int lane) { leave<FULL>(t, ok, false, lane); }
 };
 
 // Points of ray r that its tile has room for: every kernel that READS trajectories counts a ray's points through this, so
@@ -1364,35 +1391,41 @@ struct GainHeatArgs {
 };
 
 template <bool LOSS>
-__global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatArgs b) {
+__global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(const GainHeatArgs b) {
     const GainArgs& a = b.g;
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
     __syncthreads();
     const double* tab = s_tab;
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n) return;
-    const uint8_t flags = b.ray_mask ? b.ray_mask[r] : (uint8_t)1;
-    if (!flags) return;
+    // All 64 lanes of a wave stay in the point loop until the wave's longest ray has ended -- a lane without a ray, with
+    // a masked ray or past its ray's end carries live = false and computes on stale values -- so that the deposits run
+    // with every lane enabled (rt2d_deposit_full) and the loop has one wave-uniform exit.
+    const int64_t r_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool has = r_raw < a.n;
+    const int64_t r = has ? r_raw : a.n - 1;
+    const uint8_t flags = !has ? (uint8_t)0 : (b.ray_mask ? b.ray_mask[r] : (uint8_t)1);
     const bool binme = (flags & 1) != 0;
     const DevTable& ab = a.env.absorb;
-    const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
+    const int np = flags ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
+    if (!rt2d_any(np > 0)) return;
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
     const double fr = b.freq;
     const double f = fr / 1000;                                            // model_absorption.py:32
     const double ff = f * f;
     double S = 0.0, A = 0.0;
-    const int nreb = min(a.n_rebounds[r], a.rebound_cap);
+    const int nreb = flags ? min(a.n_rebounds[r], a.rebound_cap) : 0;
     int next_reb = 0;
     int next_reb_at = (nreb > 0) ? a.reb_step[r] + 1 : 0x7fffffff;         // first point index that carries the loss
-    double xp = a.X[base], zp = a.Z[base];
+    double xp = 0.0, zp = 0.0;
+    if (np > 0) { xp = a.X[base]; zp = a.Z[base]; }
     RayBinner binner;
-    binner.start(b.bin, binme, s_tab + a.env.gain_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, xp, zp, 0.0);
-    if (!binme && a.G) a.G[base] = 0.0;
-    double xn = 0.0, zn = 0.0;
+    binner.start(b.bin, binme && np > 0, s_tab + a.env.gain_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, xp, zp, 0.0);
+    if (np > 0 && !binme && a.G) a.G[base] = 0.0;
+    double xn = xp, zn = zp;
     if (np > 1) { xn = a.X[base + RT2D_WAVE]; zn = a.Z[base + RT2D_WAVE]; }
-    for (int s = 1; s < np; ++s) {
+    for (int s = 1; rt2d_any(s < np); ++s) {
+        const bool live = s < np;
         const int64_t o = base + (int64_t)s * RT2D_WAVE;
         const double x = xn, z = zn;
         if (s + 1 < np) { xn = a.X[o + RT2D_WAVE]; zn = a.Z[o + RT2D_WAVE]; }   // next point in flight during this step
@@ -1400,7 +1433,7 @@ __global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatAr
         double dL = sqrt(ddx * ddx + ddz * ddz);
         double rec[20];
         rt2d_lookup<19>(tab, ab, zp, rec);                                  // factors at the START of the segment, ray.py:346
-        while (s >= next_reb_at) {                                          // ray.py:350-362
+        while (live && s >= next_reb_at) {                                  // ray.py:350-362
             int64_t kk = (int64_t)next_reb * a.n + r;
             if (LOSS) {
                 A += a.loss[kk];
@@ -1415,13 +1448,14 @@ __global__ void __launch_bounds__(512) rt2d_gain_heatmap_kernel(const GainHeatAr
             next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
         }
         double dG = rt2d_div_1000(-1 * rt2d_alpha(rec, zp - rec[0], ff)) * dL;      // ray.py:346
-        S += dG;                                                           // ray.py:347
+        if (live) S += dG;                                                 // ray.py:347
         const double g = S + A;
-        if (binme) binner.point(b.bin, x, z, g, lane);
-        else if (a.G) a.G[o] = g;
+        binner.point<true>(b.bin, x, z, g, lane, live);                    // (a ray that is not binned here has ok = false)
+        if (live && !binme && a.G) a.G[o] = g;
         xp = x; zp = z;
     }
-    binner.finish(b.bin, lane);
+    binner.finish<true>(b.bin, lane);
+    if (!flags) return;
     if (b.irregular) b.irregular[r] = binner.violated ? 1 : 0;
     if (binner.violated && b.n_violations) atomicAdd(b.n_violations, 1ull);
     if (a.G_end) a.G_end[r] = S + A;
@@ -2374,7 +2408,9 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
     a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1; a.G = G; a.G_end = G_end;
     b.bin = make_bin_target(H, res, shape, 1.0);
     b.freq = freq; b.ray_mask = ray_mask; b.irregular = irregular; b.n_violations = (unsigned long long*)n_violations;
-    const int block = (n <= 64 * 512) ? 64 : 512;
+    static const int block_env = getenv("RT2D_GH_BLOCK") ? atoi(getenv("RT2D_GH_BLOCK")) : 0;       // development knob
+    // big fans: 3 workgroups of 4 waves per CU (with 8 waves a CU holds one workgroup: 2 waves per SIMD)
+    const int block = (block_env >= 64 && block_env <= 512) ? block_env / 64 * 64 : (n <= 64 * 512) ? 64 : 256;
     const size_t lds = ((size_t)env->dev.gain_doubles + (size_t)(block / RT2D_WAVE) * 8 * RT2D_WAVE) * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain_heatmap: absorption tables do not fit in LDS");
     void (*kern)(const GainHeatArgs) = rt2d_gain_heatmap_kernel<false>;
