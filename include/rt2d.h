@@ -247,6 +247,18 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
                           double* H, double* G, double* G_end, uint8_t* irregular, int64_t* n_violations,
                           double* loss_ws, void* stream);
 
+/* rt2d_gain_heatmap for a whole fan in one call: the rays of ray_mask value 1 are binned by the one-pass kernel, those of
+ * value 2 (turned back, left the map, too steep: RayFan.fused_mask says which) only get their gain computed by it, into
+ * a COMPACT array -- ray r at G_rest[g_slot[r] * g_room + step], g_room >= its points -- and are then binned by the
+ * general one-ray-per-workgroup kernel ("last write wins" by an LDS hash, simulation.py:120-131), which reads that array.
+ * rest_list: int32 device array, [0] = n_rest, [1] unused, [2 + k] = the k-th such ray; n_rest: the same count on the host.
+ * No gain array of the layout's size exists at any time.  Same map as rt2d_gain + rt2d_heatmap_accumulate. */
+int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                               const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
+                               const int32_t* res, const int32_t* shape, double* H,
+                               const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
+                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream);
+
 /* Distance to a target from stored trajectories (reference: ray.py:282-287). dist: device, n. */
 int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,
                   const double* target, double* dist, void* stream);

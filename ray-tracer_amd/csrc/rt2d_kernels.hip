@@ -1095,6 +1095,8 @@ struct GainArgs {
     const double* freqs; int32_t n_freqs; int64_t total;
     double* G; double* G_end;
     const double* loss;            // optional: rebound losses from rt2d_reb_loss_kernel, [(f * rebound_cap + k) * n + ray]
+    const int32_t* g_slot;         // optional (rt2d_gain_heatmap_rest): G holds only some rays, ray r at G[g_slot[r] * g_room + step]
+    int64_t g_room;
 };
 
 // Rebound losses 10*log10(refcoef) (ray.py:350-362, model_reflection.py:11-46) of every logged rebound at every
@@ -1421,7 +1423,10 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
     if (np > 0) { xp = a.X[base]; zp = a.Z[base]; }
     RayBinner binner;
     binner.start(b.bin, binme && np > 0, s_tab + a.env.gain_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, xp, zp, 0.0);
-    if (np > 0 && !binme && a.G) a.G[base] = 0.0;
+    // where this ray's gain goes when it is only computed here: its points of the tile layout, or its own row of a compact G
+    const int64_t g_base = a.g_slot ? (int64_t)a.g_slot[r] * a.g_room : base;
+    const int64_t g_step = a.g_slot ? 1 : RT2D_WAVE;
+    if (np > 0 && !binme && a.G) a.G[g_base] = 0.0;
     double xn = xp, zn = zp;
     if (np > 1) { xn = a.X[base + RT2D_WAVE]; zn = a.Z[base + RT2D_WAVE]; }
     for (int s = 1; rt2d_any(s < np); ++s) {
@@ -1451,7 +1456,7 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
         if (live) S += dG;                                                 // ray.py:347
         const double g = S + A;
         binner.point<true>(b.bin, x, z, g, lane, live);                    // (a ray that is not binned here has ok = false)
-        if (live && !binme && a.G) a.G[o] = g;
+        if (live && !binme && a.G) a.G[g_base + s * g_step] = g;
         xp = x; zp = z;
     }
     binner.finish<true>(b.bin, lane);
@@ -1547,6 +1552,7 @@ struct HeatArgs {
     int32_t split;                                  // tile kernel: waves per tile, each walking a range of rows
     // several frequencies at once (rt2d_heatmap_accumulate_multi): map f is H + f * map_stride, its gains Gs[f]
     const double* const* Gs; int32_t n_freqs; int64_t map_stride;
+    const int32_t* g_slot; int64_t g_room;          // optional: G in the compact form of GainArgs::g_slot (general kernel only)
 };
 
 // Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
@@ -1857,7 +1863,10 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                         const unsigned long long cur = s_hash[slot];
                         if (cur == HM_EMPTY) break;
                         if ((cur >> 32) == (unsigned long long)(uint32_t)cell) {
-                            if ((uint32_t)cur == (uint32_t)sx) { own[u] = cell; if (a.n_freqs == 0) gv[u] = a.G[base + (int64_t)sx * RT2D_WAVE]; }
+                            if ((uint32_t)cur == (uint32_t)sx) {
+                                own[u] = cell;
+                                if (a.n_freqs == 0) gv[u] = a.g_slot ? a.G[(int64_t)a.g_slot[r] * a.g_room + sx] : a.G[base + (int64_t)sx * RT2D_WAVE];
+                            }
                             break;
                         }
                         slot = (slot + 1) & mask;
@@ -2388,10 +2397,12 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
 }
 
 
-int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+extern "C++" {
+static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                           const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                           const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,
-                          uint8_t* irregular, int64_t* n_violations, double* loss_ws, void* stream) {
+                          uint8_t* irregular, int64_t* n_violations, double* loss_ws, void* stream,
+                          const int32_t* g_slot, int64_t g_room) {
     if (!env || !X || !Z || !tile_off || !n_pts || !reb || !res || !shape || !H) return fail("rt2d_gain_heatmap: null argument");
     if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
         return fail("rt2d_gain_heatmap: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
@@ -2408,6 +2419,7 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
     a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1; a.G = G; a.G_end = G_end;
     b.bin = make_bin_target(H, res, shape, 1.0);
     b.freq = freq; b.ray_mask = ray_mask; b.irregular = irregular; b.n_violations = (unsigned long long*)n_violations;
+    a.g_slot = g_slot; a.g_room = g_room;
     static const int block_env = getenv("RT2D_GH_BLOCK") ? atoi(getenv("RT2D_GH_BLOCK")) : 0;       // development knob
     // big fans: 3 workgroups of 4 waves per CU (with 8 waves a CU holds one workgroup: 2 waves per SIMD)
     const int block = (block_env >= 64 && block_env <= 512) ? block_env / 64 * 64 : (n <= 64 * 512) ? 64 : 256;
@@ -2424,6 +2436,15 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
     hipLaunchKernelGGL(kern, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
     HIP_OK(hipGetLastError());
     return 0;
+}
+}  // extern "C++"
+
+int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                          const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
+                          const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,
+                          uint8_t* irregular, int64_t* n_violations, double* loss_ws, void* stream) {
+    return gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H, G, G_end,
+                             irregular, n_violations, loss_ws, stream, nullptr, 0);
 }
 
 int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,
@@ -2460,7 +2481,9 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                        const int32_t* res, const int32_t* shape,
                                        double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
-                                       const double* const* Gs = nullptr, int32_t n_freqs = 0);
+                                       const double* const* Gs = nullptr, int32_t n_freqs = 0,
+                                       const int32_t* rest_list = nullptr, int64_t n_rest = 0,
+                                       const int32_t* g_slot = nullptr, int64_t g_room = 0);
 }
 
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
@@ -2475,7 +2498,8 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                        const int32_t* res, const int32_t* shape,
                                        double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
-                                       const double* const* Gs, int32_t n_freqs) {
+                                       const double* const* Gs, int32_t n_freqs,
+                                       const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room) {
     if (!X || !Z || (!G && !Gs) || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
     if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
     if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
@@ -2500,6 +2524,16 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     // (the tile kernel works on 32-bit cells: every point inside the map must have |x|, |z| < 2^31)
     const bool small_coords = res[0] < (1 << 20) && res[1] < (1 << 20) &&
                               (int64_t)shape[0] * res[0] < (1ll << 31) && (int64_t)shape[1] * res[1] < (1ll << 31);
+    a.g_slot = g_slot; a.g_room = g_room;
+    if (rest_list) {
+        // the caller's own list of rays ([0] = their number, [2 + k] = ray ids), all of them for the general kernel
+        a.work = const_cast<int32_t*>(rest_list);
+        const int64_t blocks = n_rest < 16384 ? (n_rest + 127) / 128 * 128 : 16384;
+        if (blocks > 0)
+            hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(HM_THREADS), (size_t)a.cap * 8 + (size_t)a.cell_cap * 4, stream, a);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
     const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays && small_coords;
     if (work && !fast) HIP_OK(hipMemsetAsync(work, 0xff, sizeof(int32_t), stream));     // work[0] = -1: every ray went general
     if (fast) {
@@ -2580,6 +2614,21 @@ int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const do
     if (!Gs) return fail("rt2d_heatmap_accumulate_multi: null argument");
     if (n_freqs <= 0) return n_freqs == 0 ? 0 : fail("rt2d_heatmap_accumulate_multi: negative frequency count");
     return heatmap_accumulate_impl(X, Z, nullptr, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream, Gs, n_freqs);
+}
+
+int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                               const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
+                               const int32_t* res, const int32_t* shape, double* H,
+                               const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
+                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream) {
+    if (n_rest < 0 || (n_rest > 0 && (!rest_list || !g_slot || !G_rest || g_room <= 0)))
+        return fail("rt2d_gain_heatmap_rest: rest_list, g_slot, G_rest and g_room describe the rays of ray_mask value 2");
+    int32_t rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
+                                   n_rest > 0 ? G_rest : nullptr, nullptr, nullptr, n_violations, loss_ws, stream,
+                                   n_rest > 0 ? g_slot : nullptr, g_room);
+    if (rc || n_rest == 0) return rc;
+    return heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, (hipStream_t)stream,
+                                   nullptr, 0, rest_list, n_rest, g_slot, g_room);
 }
 
 int32_t rt2d_heatmap_finalize_multi(const double* H, const int32_t* shape, int32_t n_maps, double cutoff, double reduction_power,

@@ -30,6 +30,7 @@ SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below
 # (SPECULATIVE_ROOM points of room per ray) that is then kept as the fan's layout -- untouched pages cost nothing -- as
 # long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
 PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
+STREAM_MIN_RAYS = int(os.environ.get('RT2D_STREAM_MIN_RAYS', 1 << 19))    # fans from here on bin through the one-pass kernel
 SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat map hands rays to the stored path
 LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
 
@@ -43,6 +44,18 @@ def _torch():
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """The second stream of a device (small side fans run on it beside the big kernel of the main stream)."""
+    torch = _torch()
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 _FREQ_TENSORS = {}
@@ -571,6 +584,10 @@ class RayFan:
                 loss = torch.empty(cap * self.n, dtype=torch.float64, device=self.device)
                 fr = _freq_tensor([freq], self.device)
                 _lib.check(L.rt2d_rebound_loss(handle, C.byref(self._out), cap, self.n, fr.data_ptr(), 1, loss.data_ptr(), stream))
+            # (the rays the fused kernel cannot take are known before it starts: they go through the stored path on a
+            # second stream while it runs)
+            rest = torch.nonzero(sel & (mask == 0)).flatten()
+            before = torch.cuda.current_stream().record_event()
             rc = L.rt2d_cast_heatmap(handle, self.angles_dev.data_ptr(), self.n, src,
                                      C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
                                      res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(), _ptr(loss), cap, stream)
@@ -578,46 +595,69 @@ class RayFan:
                 # the fused kernel cannot take this environment (its tables do not fit in LDS) or these parameters
                 # (power_cutoff): every ray goes through the stored path, a chunk at a time
                 self.fused_unavailable = L.rt2d_last_error().decode()
-                mask = torch.zeros_like(mask)
-            rest = torch.nonzero(sel & (mask == 0)).flatten()
-            self.last_slow_rays = int(rest.numel())
+                rest = torch.nonzero(sel).flatten()
             self.last_fused_violations = viol
+            self._bin_side_rays(rest, H, res, shape, freq, dropped, fast=rc != 0, after=before)
+
+    def _bin_side_rays(self, rest, H, res, shape, freq, dropped, fast=False, after=None):
+        """Adds the rays `rest` (device index tensor) to H through the stored path -- cast with trajectories as side
+        fans of at most SIDE_FAN_RAYS rays, gain, general binner -- on a second stream, so that their few long waves
+        run beside the kernel that bins everybody else; the calling stream waits for them at the end.  after: an event
+        recorded on the calling stream BEFORE that kernel was queued (the side stream starts from there, not behind it)."""
+        torch = _torch()
+        self.last_slow_rays = int(rest.numel())
+        if self.last_slow_rays == 0:
+            return
+        main = torch.cuda.current_stream()
+        side_stream = _side_stream(self.device)
+        if after is not None:
+            side_stream.wait_event(after)                # H is zeroed, the angles are there
+        else:
+            side_stream.wait_stream(main)
+        with torch.cuda.stream(side_stream):
             for c0 in range(0, int(rest.numel()), SIDE_FAN_RAYS):
                 part = rest[c0:c0 + SIDE_FAN_RAYS]
                 init = None if self._init[0] is None else (self._init[0][part].cpu().numpy(), self._init[1][part].cpu().numpy())
                 side = RayFan(self.env, self.source, self.angles_dev[part], target=None, store=True, device=self.device,
                               init=init, **dict(self.kw))
-                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=rc != 0)
+                side.validate()                          # (a ray that outgrew the provisional room: cast again, now)
+                side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=fast, stream=False)
                 del side
+        main.wait_stream(side_stream)
 
     def heatmap_accumulate_stream(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
-        """Gain and binning in ONE forward pass over the stored trajectories (rt2d_gain_heatmap): the gain array is never
-        written for the rays that pass can bin (fused_mask); the others get their gain stored by the same pass and are
-        binned by the general kernel.  Same map as populate(freq) + heatmap_accumulate."""
+        """Gain and binning in ONE forward pass over the stored trajectories (rt2d_gain_heatmap_rest): no gain array of the
+        layout's size exists.  The rays that pass cannot bin (fused_mask: turned back, left the map, too steep for its
+        eight row slots) only get their gain from it, into one row each of a compact array, and the general kernel bins
+        them from there.  Same map as populate(freq) + heatmap_accumulate."""
         self._need_store()
         torch = _torch()
         L = _lib.lib()
         with torch.cuda.device(self.device):
+            self.validate()                              # the masks below need the final cast
             stream = torch.cuda.current_stream().cuda_stream
             sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
             m = self.fused_mask(res, shape, ray_mask)
             rest = sel & (m == 0)
+            # the rays the one pass cannot bin: it computes their gain into one row each of a compact array and the general
+            # kernel bins them from there (rt2d_gain_heatmap_rest)
+            slot = torch.cumsum(rest, 0, dtype=torch.int32) - 1
+            idx = torch.nonzero(rest).flatten().to(torch.int32)
+            n_rest = int(idx.numel())
             m = m + 2 * rest.to(torch.uint8)
-            n_rest = int(rest.sum().item())
-            G = torch.empty(self.total, dtype=torch.float64, device=self.device) if n_rest else None
+            g_room = int(self._summary[1]) // TILE if self._summary is not None else int(self.n_pts.max().item())
+            G_rest = torch.empty(max(1, n_rest * g_room), dtype=torch.float64, device=self.device)
+            rest_list = torch.cat([torch.tensor([n_rest, 0], dtype=torch.int32, device=self.device), idx])
             viol = torch.zeros(1, dtype=torch.int64, device=self.device)
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
             ws_elems = self.rebound_cap * self.n
             loss_ws = torch.empty(ws_elems, dtype=torch.float64, device=self.device) if 0 < ws_elems * 8 <= LOSS_WS_BYTES else None
-            _lib.check(L.rt2d_gain_heatmap(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
-                                           self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap,
-                                           self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(), _ptr(G), None, None,
-                                           viol.data_ptr(), _ptr(loss_ws), stream))
-            if n_rest:
-                _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), G.data_ptr(), self.tile_off.data_ptr(),
-                                                     self.n_pts.data_ptr(), self.n, rest.to(torch.uint8).data_ptr(), res_c, shape_c,
-                                                     H.data_ptr(), _ptr(dropped), None, stream))
+            _lib.check(L.rt2d_gain_heatmap_rest(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
+                                                self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap,
+                                                self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(),
+                                                rest_list.data_ptr(), n_rest, slot.data_ptr(), g_room, G_rest.data_ptr(),
+                                                _ptr(dropped), viol.data_ptr(), _ptr(loss_ws), stream))
             self.last_slow_rays = n_rest
             self.last_fused_violations = viol
 
@@ -660,11 +700,15 @@ class RayFan:
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
         fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests).
         stream=True: gain + binning in one pass (heatmap_accumulate_stream): the gain array (8 B per point) is never
-        allocated.  Off by default: measured on 1M rays the one-pass kernel (214 vector registers, 8 waves per CU) takes
-        17.5 ms against 6.9 + 8.2 ms for rt2d_gain followed by the tile kernel.
+        allocated.  The default for fans of STREAM_MIN_RAYS rays and more whose gain at freq is not there yet: on 1M rays
+        the one pass takes 9.1 + 1.7 ms (its kernel, then the general kernel for the rays it cannot bin) against 5.5 +
+        6.6 ms for rt2d_gain followed by the tile kernel, and needs no gain array (8 B per point of the layout); a fan
+        of 131 072 rays is too few waves for its ray-sequential walk (5.6 against 4.9 ms for the whole cast + map).
         A fan cast with store=False goes through the fused kernel (heatmap_accumulate_fused)."""
         if not self.store:
             return self.heatmap_accumulate_fused(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
+        if stream is None:
+            stream = fast and freq not in self.G and self.n >= STREAM_MIN_RAYS
         if stream:
             return self.heatmap_accumulate_stream(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
         torch = _torch()
