@@ -536,28 +536,55 @@ def main():
                 'hbm_bytes_pmc': pb['hbm_bytes'], 'l2_atomics_pmc': pb['atomics'],
                 'atomics_per_s': None if pb['atomics'] is None else pb['atomics'] / t_bin,
                 'points_per_atomic': None if not pb['atomics'] else sl / pb['atomics'], 'pmc_source': pb['source']}
-        # the fused pipeline on the same fan (no trajectory in HBM)
-        _, hm_f = one_step_fused(rt, torch, env, source, big_angles, device=device)
+        # The same product WITHOUT keeping trajectories, through the product API: Simulation2D.cast(store=False) is lazy for a
+        # fan this big, and heatmap() then casts it chunk by chunk WITH trajectories, bins each chunk through the stored
+        # pipeline and drops it (RayFan.heatmap_accumulate_chunked): no counting pass, per-ray results as a by-product,
+        # never more than a chunk's trajectories in HBM.
+        from ray_tracer_amd import rays as rays_mod
+
+        def frugal_step():
+            sim_f = rt.Simulation2D(env, source)
+            fan_f = sim_f.cast(big_angles, store=False, **PROP)
+            hm = sim_f.heatmap(resolution=list(RES), cutoff=CUTOFF, reduction_power=.5, as_tensor=True)
+            return fan_f, hm
+        frugal_step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.large_steps):
+            fan_f, hm_f = frugal_step()
+        torch.cuda.synchronize(); dtf = time.perf_counter() - t0
+        sf = ray_steps_of(fan_f.n_pts, fan_f.status)
+        result['large_fan_fused'] = {
+            'rays': nL, 'ray_steps': sf, 'value': sf * args.large_steps / dtf, 'unit': 'ray-steps/s',
+            's_per_heatmap': dtf / args.large_steps,
+            'path': 'Simulation2D.cast(store=False) + heatmap(): lazy fan, chunked cast-with-trajectories -> bin -> drop on two '
+                    'streams (no counting pass)',
+            'chunk_rays': rays_mod.CHUNK_RAYS, 'passes': fan_f.passes,
+            'rays_binned_by_the_general_kernel': int(fan_f.last_slow_rays),
+            'max_abs_diff_vs_stored_map': float((hm_f - hm_l).abs().max().item())}
+        del fan_f, hm_f
+        # ... and the fused KERNEL (rt2d_cast_heatmap: cast -> gain -> binning in registers, nothing stored at all) behind a
+        # counting pass, which the chunked path replaced as the default for big fans
+        _, hm_k = one_step_fused(rt, torch, env, source, big_angles, device=device)
         recs = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(args.large_steps):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            fan_f, hm_f = one_step_fused(rt, torch, env, source, big_angles, ev=ev, device=device)
+            fan_k, hm_k = one_step_fused(rt, torch, env, source, big_angles, ev=ev, device=device)
             recs.append(ev)
-        torch.cuda.synchronize(); dtf = time.perf_counter() - t0
+        torch.cuda.synchronize(); dtk = time.perf_counter() - t0
         names = ('cast_count', 'fused_cast_gain_bin+rest', 'finalize')
         stf = {nm: float(np.mean([e[k].elapsed_time(e[k + 1]) for e in recs])) for k, nm in enumerate(names)}
-        sf = ray_steps_of(fan_f.n_pts, fan_f.status)
-        result['large_fan_fused'] = {
-            'rays': nL, 'ray_steps': sf, 'value': sf * args.large_steps / dtf, 'unit': 'ray-steps/s',
-            's_per_heatmap': dtf / args.large_steps, 'stage_ms': stf,
-            'rays_binned_by_the_stored_path': int(fan_f.last_slow_rays),
-            'fused_violations': int(fan_f.last_fused_violations.item()),
-            'max_abs_diff_vs_stored_map': float((hm_f - hm_l).abs().max().item()),
-            'fp64_valu_frac': sf * (FLOP_PER_STEP + 30) / (stf['fused_cast_gain_bin+rest'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+        sk = ray_steps_of(fan_k.n_pts, fan_k.status)
+        result['large_fan_fused']['fused_kernel'] = {
+            's_per_heatmap': dtk / args.large_steps, 'stage_ms': stf,
+            'rays_binned_by_the_stored_path': int(fan_k.last_slow_rays),
+            'fused_violations': int(fan_k.last_fused_violations.item()),
+            'max_abs_diff_vs_stored_map': float((hm_k - hm_l).abs().max().item()),
+            'fp64_valu_frac': sk * (FLOP_PER_STEP + 30) / (stf['fused_cast_gain_bin+rest'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
             # the counting pass stores nothing: stepping alone, the FP64 vector figure of the cast kernel
-            'count_pass_steps_per_s': sf / (stf['cast_count'] * 1e-3),
-            'count_pass_fp64_valu_frac': sf * FLOP_PER_STEP / (stf['cast_count'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
+            'count_pass_steps_per_s': sk / (stf['cast_count'] * 1e-3),
+            'count_pass_fp64_valu_frac': sk * FLOP_PER_STEP / (stf['cast_count'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
+        del fan_k, hm_k
         # the same fan over a bathymetry cut (BASELINE configs 3 / 5: the floor is a table cut out of an ESRI grid;
         # the reference's data/asc file is absent, so the synthetic grid of the parity fixtures stands in)
         asc = os.path.join(ROOT, 'tests', 'golden', 'synth_bathy.asc')

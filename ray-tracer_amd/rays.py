@@ -31,6 +31,10 @@ SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below
 # long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
 PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
 STREAM_MIN_RAYS = int(os.environ.get('RT2D_STREAM_MIN_RAYS', 1 << 19))    # fans from here on bin through the one-pass kernel
+CHUNK_RAYS = int(os.environ.get('RT2D_CHUNK_RAYS', 1 << 19))           # rays cast with trajectories at a time by the chunked heat map
+CHUNKED_MIN_RAYS = int(os.environ.get('RT2D_CHUNKED_MIN_RAYS', 1 << 18))   # store=False fans from here on use it (smaller: fused kernel)
+CHUNK_STREAMS = int(os.environ.get('RT2D_CHUNK_STREAMS', 2))
+SIDE_STREAM = os.environ.get('RT2D_SIDE_STREAM', '1') != '0'      # side fans of the fused heat map on a second stream
 SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat map hands rays to the stored path
 LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
 
@@ -49,10 +53,10 @@ def _ptr(t):
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    """The second stream of a device (small side fans run on it beside the big kernel of the main stream)."""
+def _side_stream(device, which=0):
+    """A second (third, ...) stream of a device (small side fans run on it beside the big kernel of the main stream)."""
     torch = _torch()
-    key = (device.type, device.index)
+    key = (device.type, device.index, which)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
@@ -83,7 +87,20 @@ class RayFan:
                               n_steps_max=N_STEPS_MAX, n_rebounds_max=N_REBOUNDS_MAX,
                               power_cutoff=0., cutoff_freq=1.)
 
-    def __init__(self, env, source, angles, target=None, store=True, device=None, init=None, store_c=False, **kwargs):
+    # what _cast produces: asking an uncast (lazy) fan for any of these casts it first
+    _CAST_FIELDS = frozenset(('range', 'slope_max', 'n_pts', 'stop_code', 'n_rebounds', 'status', 'monotone', '_scalars', 'dist',
+                              'step_target', 'T_target', '_init', 'rebound_cap', 'tile_off', 'X', 'Z', 'Cpt', 'total', 'padded',
+                              'passes', '_out', 'reb_velocity', 'reb_angle', 'reb_pos_x', 'reb_pos_z', 'reb_step', 'reb_surface'))
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        if d.get('_uncast') and name in RayFan._CAST_FIELDS:
+            d['_uncast'] = False
+            self._cast(d.get('_init_host'), False)
+            return getattr(self, name)
+        raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
+
+    def __init__(self, env, source, angles, target=None, store=True, device=None, init=None, store_c=False, lazy=False, **kwargs):
         torch = _torch()
         self.env = env
         self.source = np.asarray(source, dtype=np.float64)
@@ -107,7 +124,12 @@ class RayFan:
         self._force_exact = False
         self._summary = None
         self._init_host = init
-        self._cast(init, store_c)
+        self._lazy_store = False
+        # lazy (store=False only): nothing is cast until something asks for a per-ray result -- a heat map asked for first
+        # (heatmap_accumulate_chunked) then produces them on its way, and no counting pass ever runs
+        self._uncast = bool(lazy) and not self.store and self.n > 0
+        if not self._uncast:
+            self._cast(init, store_c)
 
     # -- casting ----------------------------------------------------------------------------------
     def _params(self, rebound_cap):
@@ -122,7 +144,7 @@ class RayFan:
         p.power_cutoff, p.cutoff_freq = float(self.kw['power_cutoff']), float(self.kw['cutoff_freq'])
         return p
 
-    def _cast(self, init, store_c, known_n_pts=None):
+    def _cast(self, init, store_c, known_n_pts=None, alloc_only=False):
         torch = _torch()
         kwargs_keep_log = self.keep_log
         L = _lib.lib()
@@ -206,7 +228,7 @@ class RayFan:
             self.total = 0
             self.padded = False
             self.passes = 'count'
-            if n == 0:
+            if n == 0 or alloc_only:
                 return
             if not self.store:
                 # scalars only: one pass with the post-pass folded in.  With a bounded rebound count the rebound log is kept
@@ -396,7 +418,7 @@ class RayFan:
         sub._angles_host = None if self._angles_host is None else self._angles_host[np.asarray(indices, dtype=np.int64)]
         sub.n = int(idx.numel())
         sub._host, sub.G, sub.G_end, sub._post = {}, {}, {}, None
-        sub._pending, sub._force_exact, sub._summary, sub._scalars = False, False, None, None
+        sub._pending, sub._force_exact, sub._summary, sub._scalars, sub._uncast = False, False, None, None, False
         init = None
         if self._init_host is not None:
             sel = np.asarray(indices, dtype=np.int64)
@@ -609,8 +631,10 @@ class RayFan:
         if self.last_slow_rays == 0:
             return
         main = torch.cuda.current_stream()
-        side_stream = _side_stream(self.device)
-        if after is not None:
+        side_stream = _side_stream(self.device) if SIDE_STREAM else main
+        if side_stream is main:
+            pass
+        elif after is not None:
             side_stream.wait_event(after)                # H is zeroed, the angles are there
         else:
             side_stream.wait_stream(main)
@@ -623,7 +647,81 @@ class RayFan:
                 side.validate()                          # (a ray that outgrew the provisional room: cast again, now)
                 side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=fast, stream=False)
                 del side
-        main.wait_stream(side_stream)
+        if side_stream is not main:
+            main.wait_stream(side_stream)
+
+    def heatmap_accumulate_chunked(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
+        """Heat map of a fan that keeps no trajectories (store=False), CHUNK_RAYS rays at a time: the chunk is cast WITH
+        trajectories, binned by the stored pipeline, and dropped again -- the trajectories in memory are never more than
+        one chunk's.  A lazy fan that has not been cast yet gets its per-ray results from those casts (single storing pass
+        into a provisional layout each): no counting pass runs at all.  A fan that was counted before casts every chunk
+        straight into its exact layout.  Returns False when a chunk outgrew its provisional layout: H is then incomplete,
+        the fan has been cast (counted) the ordinary way, and the caller starts over with a zeroed map.  Same map as
+        heatmap_accumulate of the same fan cast with store=True."""
+        torch = _torch()
+        L = _lib.lib()
+        first = bool(self.__dict__.get('_uncast'))
+        n = self.n
+        with torch.cuda.device(self.device):
+            if first:
+                self._uncast = False
+                self._cast(self._init_host, False, alloc_only=True)
+            checks, slow, slows = [], 0, []
+            # chunks alternate between two streams, each starting when the previous chunk's CAST is done: the long last
+            # waves of one chunk's kernels (a chunk is one round of waves: its kernels last as long as its longest ray)
+            # run beside the next chunk's
+            main = torch.cuda.current_stream()
+            lanes = [main] + ([_side_stream(self.device, w) for w in range(CHUNK_STREAMS - 1)] if SIDE_STREAM and n > CHUNK_RAYS else [])
+            cast_done = None
+            for k, c0 in enumerate(range(0, n, CHUNK_RAYS)):
+              lane_stream = lanes[k % len(lanes)]
+              if cast_done is not None and lane_stream is not main:
+                  lane_stream.wait_event(cast_done)
+              with torch.cuda.stream(lane_stream):
+                c1 = min(n, c0 + CHUNK_RAYS)
+                if first:
+                    init = None if self._init_host is None else (np.asarray(self._init_host[0])[c0:c1], np.asarray(self._init_host[1])[c0:c1])
+                    sub = RayFan(self.env, self.source, self.angles_dev[c0:c1], target=self.target, store=True, device=self.device,
+                                 init=init, **dict(self.kw))
+                    for name in ('n_pts', 'stop_code', 'n_rebounds', 'status', 'monotone', 'slope_max', 'dist', 'step_target', 'T_target'):
+                        t = getattr(self, name)
+                        if t is not None:
+                            t[c0:c1].copy_(getattr(sub, name))
+                    self.range[:, c0:c1].copy_(sub.range)
+                    if sub._pending:
+                        checks.append((sub._summary_dev, sub._room))
+                else:
+                    sub = self.subset(np.arange(c0, c1))
+                    sub._need_store()
+                cast_done = lane_stream.record_event()
+                mask = (sub.status == 0) if ray_mask is None else ((sub.status == 0) & (ray_mask[c0:c1] != 0))
+                sub._pending = False                    # (checked below for all chunks at once)
+                sub.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask.to(torch.uint8), dropped=dropped,
+                                       stream=None if os.environ.get('RT2D_CHUNK_ONEPASS') else False)
+                w = getattr(sub, '_last_slow', 0)           # an int, or the work list of rt2d_heatmap_accumulate ([0] < 0: every ray)
+                slows.append(w if isinstance(w, int) else torch.where(w[0] < 0, torch.full_like(w[0], sub.n), w[0]))
+                del sub
+            for lane_stream in lanes[1:]:
+                main.wait_stream(lane_stream)
+            for w in slows:
+                slow = slow + w
+            self.last_fused_violations = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._last_slow = slow if isinstance(slow, int) else slow.reshape(1)
+            if first:
+                stream = torch.cuda.current_stream().cuda_stream
+                n_tiles = (n + TILE - 1) // TILE
+                exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=self.device)
+                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
+                self._queue_summary(exact, stream)
+                self.passes = 'chunked'
+                # -- the one read: every chunk's summary and the fan's own --
+                got = torch.cat([c for c, _ in checks] + [self._summary_dev]).tolist()
+                for k, (_, room) in enumerate(checks):
+                    if int(got[8 * k + 1]) > room * TILE or bool(got[8 * k + 2]):
+                        self._cast(self._init_host, False)          # cast the ordinary way; the caller starts over
+                        return False
+                self._summary = got[-8:]
+        return True
 
     def heatmap_accumulate_stream(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
         """Gain and binning in ONE forward pass over the stored trajectories (rt2d_gain_heatmap_rest): no gain array of the
@@ -706,6 +804,14 @@ class RayFan:
         of 131 072 rays is too few waves for its ray-sequential walk (5.6 against 4.9 ms for the whole cast + map).
         A fan cast with store=False goes through the fused kernel (heatmap_accumulate_fused)."""
         if not self.store:
+            if self.__dict__.get('_uncast') or self.n >= CHUNKED_MIN_RAYS:
+                if self.heatmap_accumulate_chunked(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped):
+                    return
+                H.zero_()                        # a chunk outgrew its provisional layout: again, with counted sizes
+                if dropped is not None:
+                    dropped.zero_()
+                self.heatmap_accumulate_chunked(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
+                return
             return self.heatmap_accumulate_fused(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
         if stream is None:
             stream = fast and freq not in self.G and self.n >= STREAM_MIN_RAYS

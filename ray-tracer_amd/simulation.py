@@ -13,6 +13,7 @@ import numpy as np
 
 from .rays import RayFan, RayPack2D, _torch
 from . import _lib
+from . import rays as rays_mod
 from . import parallel
 
 
@@ -66,13 +67,21 @@ class Simulation2D:
         if pack not in self.raypacks:
             self.raypacks[pack] = RayPack2D()
         raypack = self.raypacks[pack]
-        if len(angles) == 1 and np.ndim(angles[0]) == 1:
+        if len(angles) == 1 and (np.ndim(angles[0]) == 1 or hasattr(angles[0], 'data_ptr')):
             angles = angles[0]
-        angles = np.asarray(angles, dtype=np.float64)
+        on_device = hasattr(angles, 'data_ptr') and getattr(angles, 'is_cuda', False)      # a device tensor is used where it is
+        if on_device and self.distributed and parallel.active():
+            angles, on_device = angles.cpu().numpy(), False
+        if not on_device:
+            angles = np.asarray(angles, dtype=np.float64)
         if self.distributed and parallel.active():
             angles, _ = parallel.shard_angles(angles, mode=kwargs.get('shard', self.shard))
             raypack.sharded = True            # this pack holds one rank's share: heatmap() combines the ranks
-        fan = RayFan(self.env, self.source, angles, target=kwargs.get('target', None), store=kwargs.get('store', True),
+        store = kwargs.get('store', True)
+        # a big fan without trajectories is cast lazily: if a heat map is the first thing asked of it, the chunked heat
+        # map casts it on its way (RayFan.heatmap_accumulate_chunked) and no counting pass runs
+        lazy = (not store) and kwargs.get('target', None) is None and len(angles) >= rays_mod.CHUNKED_MIN_RAYS
+        fan = RayFan(self.env, self.source, angles, target=kwargs.get('target', None), store=store, lazy=lazy,
                      **{k: kwargs[k] for k in RayFan.PROPAGATE_DEFAULTS if k in kwargs})
         if kwargs.get('strict', False) and bool((fan.status == _lib.RAY_ERR_INTERP).any().item()):
             raise ValueError('A value in x_new is outside the interpolation range.')
@@ -99,7 +108,8 @@ class Simulation2D:
         env = self.env
         lo = np.minimum(0., np.asarray(env.range_min, dtype=np.float64))
         hi = np.maximum(0., np.asarray(env.range_max, dtype=np.float64))
-        if lo[0] <= -1 or hi[1] >= 1 + 1e-9 or fan.n == 0 or not fan._pending:
+        lazy = bool(fan.__dict__.get('_uncast'))
+        if lo[0] <= -1 or hi[1] >= 1 + 1e-9 or fan.n == 0 or not (fan._pending or lazy):
             return None
         shape_b = parallel.heatmap_shape(lo, hi, res)
         if int(shape_b[0]) * int(shape_b[1]) >= (1 << 28):
@@ -119,9 +129,14 @@ class Simulation2D:
                     distinct = (a[1:] > a[:-1]).all() | (a[1:] < a[:-1]).all()
             H = torch.zeros(int(shape_b[0]) * int(shape_b[1]), dtype=torch.float64, device=device)
             dropped = torch.zeros(1, dtype=torch.int64, device=device)
-            mask = (fan.status == 0).to(torch.uint8)
-            fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
-                                   fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
+            if lazy:
+                # no trajectories kept and nothing cast yet: chunk by chunk (cast with trajectories -> bin -> drop)
+                if not fan.heatmap_accumulate_chunked(H, res, shape_b, freq=kwargs.get('freq', 1), dropped=dropped):
+                    return None
+            else:
+                mask = (fan.status == 0).to(torch.uint8)
+                fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
+                                       fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
             out_b = None
             if finalize:
                 out_b = torch.empty((int(shape_b[1]), int(shape_b[0])), dtype=torch.float64, device=device)
@@ -153,7 +168,7 @@ class Simulation2D:
         raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
         dist_on = getattr(raypack, 'sharded', False) and parallel.active()
         fan = raypack._sole_pending_fan()
-        if fan is not None and fan.store and not dist_on and not kwargs.get('stream', None):
+        if fan is not None and (fan.store or fan.__dict__.get('_uncast')) and not dist_on and not kwargs.get('stream', None):
             got = self._heatmap_one_fan(fan, res, kwargs, finalize)
             if got is not None:
                 Hb, out_b, shape, dropped = got
