@@ -12,9 +12,10 @@ config 1: 999 rays (angles -i/1000), 20 rebounds, dx_max 50 / dz_max 25, floor m
 all-reduces of ray-tracer_amd/parallel.py.
 
 Prints ONE JSON line on rank 0: metric ray-steps/s (whole job), per-stage kernel times from HIP events,
-`roofline` of the dominant kernel (the storing cast: 16 B per ray-step against HBM), a `large_fan` block
-(the same pipeline on --large-rays rays, where the GPU is actually full) and `cpu_baseline`
-(oracle/rt2d_oracle.c, scalar, 1 core, same fan).
+`roofline` of the dominant kernel (the storing cast: 48 flop per ray-step against the FP64 vector ALU first, 16 B
+per ray-step against HBM second; the PMC traffic only from a committed profile of THIS build), a `large_fan` block
+(the same pipeline on --large-rays rays, where the GPU is actually full), `large_fan_fused` (the same map without
+keeping trajectories) and `cpu_baseline` (oracle/rt2d_oracle.c, scalar, 1 core, same fan).
 """
 
 import argparse
@@ -247,15 +248,33 @@ def pmc_traffic(large):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', '*_traffic.json')))
     if not files:
-        return None, None
+        return None, 'no PMC profile committed under profiles/'
     with open(files[-1]) as f:
-        k = json.load(f)['kernels']
+        prof = json.load(f)
+    stale = profile_is_stale(prof)
+    if stale:
+        return None, f'{os.path.relpath(files[-1], ROOT)}: {stale}'
+    k = prof['kernels']
     cand = [(int(name.split('grid=')[1].split('|')[0]), v) for name, v in k.items()
             if name.startswith('rt2d_cast_kernel<true') and v.get('hbm_bytes') is not None]
     if not cand:
-        return None, None
+        return None, f'{os.path.relpath(files[-1], ROOT)} has no FETCH_SIZE / WRITE_SIZE pass of the storing cast'
     cand.sort(key=lambda c: c[0])
     return (cand[-1] if large else cand[0])[1]['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+
+
+def profile_is_stale(prof):
+    """None when the committed profile measured THIS build (hash of the kernel sources, stamped by tools/profile_gpu.sh),
+    else the reason its counters are not reported."""
+    import rt2d_loader
+    here = rt2d_loader.load()._lib.source_hash()
+    b = prof.get('build')
+    if not b or not b.get('source_sha256'):
+        return 'profile carries no build stamp (taken before round 2)'
+    if b['source_sha256'] != here:
+        return (f"profile measured kernel sources {b['source_sha256']} (commit {str(b.get('git_head'))[:10]}), "
+                f"this build is {here}: counters not carried over")
+    return None
 
 
 def pmc_binning():
@@ -270,7 +289,12 @@ def pmc_binning():
         return rows
     names = ('rt2d_heatmap_fast_kernel<1>', 'rt2d_heatmap_kernel')
     if tf:
-        rows = big(json.load(open(tf[-1]))['kernels'], names)
+        prof = json.load(open(tf[-1]))
+        stale = profile_is_stale(prof)
+        if stale:
+            out['source'] = f'{os.path.relpath(tf[-1], ROOT)}: {stale}'
+            return out
+        rows = big(prof['kernels'], names)
         if rows and all(r.get('hbm_bytes') is not None for r in rows):
             out['hbm_bytes'] = sum(r['hbm_bytes'] for r in rows)
             out['source'] = os.path.relpath(tf[-1], ROOT)
@@ -279,6 +303,24 @@ def pmc_binning():
         if rows and all('TCC_ATOMIC_sum' in r for r in rows):
             out['atomics'] = sum(r['TCC_ATOMIC_sum'] for r in rows)
     return out
+
+
+def roofline_block(kernel, steps, ms, traffic, traffic_src, note=None):
+    """The stepping kernel is priced against the FP64 vector ALU first (48 flop per ray-step, no MFMA shape in
+    it), the HBM roof of its storing instance second (16 B per ray-step).  `traffic`: HBM bytes per launch from the PMC passes
+    of the committed profile of THIS build, else null with the reason in traffic_source."""
+    t = ms * 1e-3
+    tf = steps * FLOP_PER_STEP / t / 1e12
+    gb = steps * BYTES_PER_STEP / t / 1e9
+    r = {'kernel': kernel, 'bound': 'fp64_vector', 'achieved': tf, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+         'frac': tf / FP64_VECTOR_PEAK_TFLOPS, 'algorithmic_flop': steps * FLOP_PER_STEP, 'flop_per_ray_step': FLOP_PER_STEP,
+         'traffic': traffic, 'traffic_source': traffic_src,
+         'secondary': {'bound': 'hbm', 'achieved': gb, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gb / HBM_PEAK_GBS,
+                       'algorithmic_bytes': steps * BYTES_PER_STEP, 'bytes_per_ray_step': BYTES_PER_STEP},
+         'launch_ms': ms}
+    if note:
+        r['note'] = note
+    return r
 
 
 def one_step_fused(rt, torch, env, source, angles_dev, ev=None, device=None):
@@ -456,7 +498,6 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = steps_all * args.steps / dt
         store_ms = st['cast_store']
-        achieved = steps_rank * BYTES_PER_STEP / (store_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(large=False)
         result = {
             'metric': 'ray-steps/sec (node) + s per 999-ray 20-rebound heatmap', 'value': value, 'unit': 'ray-steps/s',
@@ -470,11 +511,9 @@ def main():
             'timed_path': 'product API: Simulation2D.cast + Simulation2D.heatmap (one device -> host read per heat map)',
             'product_api_ms': ms_per_step, 'raw_abi_ms': dt_raw / args.steps * 1e3,
             'stage_ms': st,
-            'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_source': traffic_src, 'algorithmic_bytes': steps_rank * BYTES_PER_STEP,
-                         'note': '999 rays = 250 wavefronts of 4 rays, one per CU: bound by the dependent-instruction latency of a lone wave (DESIGN.md section 6); see large_fan for the full chip',
-                         'fp64_valu_frac': steps_rank * FLOP_PER_STEP / (store_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+            'roofline': roofline_block('rt2d_cast_kernel<WRITE=true>', steps_rank, store_ms, traffic, traffic_src,
+                                       note='999 rays = 250 wavefronts of 4 rays, one per CU: bound by the dependent-instruction '
+                                            'latency of a lone wave (DESIGN.md section 6); see large_fan for the full chip'),
         }
 
     # N > 1: the 1M-ray fan of the single-GPU block below, SHARDED over the ranks (strong scaling: north_star's "1M-ray
@@ -516,15 +555,11 @@ def main():
         torch.cuda.synchronize(); dtl = time.perf_counter() - t0
         sl = ray_steps_of(n_pts_l, status_l)
         stl = stages_l.summary()
-        ach = sl * BYTES_PER_STEP / (stl['cast_store'] * 1e-3) / 1e9
-        traffic_l, traffic_src_l = pmc_traffic(large=True) if nL == (1 << 20) else (None, None)
+        traffic_l, traffic_src_l = pmc_traffic(large=True) if nL == (1 << 20) else (None, 'the committed profile is of the 1 048 576-ray fan')
         result['large_fan'] = {
             'rays': nL, 'ray_steps': sl, 'value': sl * args.large_steps / dtl, 'unit': 'ray-steps/s',
             's_per_heatmap': dtl / args.large_steps, 'stage_ms': stl,
-            'roofline': {'kernel': 'rt2d_cast_kernel<WRITE=true>', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_l,
-                         'traffic_source': traffic_src_l, 'algorithmic_bytes': sl * BYTES_PER_STEP,
-                         'fp64_valu_frac': sl * FLOP_PER_STEP / (stl['cast_store'] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+            'roofline': roofline_block('rt2d_cast_kernel<WRITE=true>', sl, stl['cast_store'], traffic_l, traffic_src_l),
         }
         if nL == (1 << 20):
             pb = pmc_binning()

@@ -22,10 +22,60 @@ EXPORTS = ['rt2d_last_error', 'rt2d_version', 'rt2d_env_create', 'rt2d_env_destr
            'rt2d_heatmap_accumulate', 'rt2d_heatmap_accumulate_noalloc', 'rt2d_heatmap_accumulate_multi', 'rt2d_heatmap_finalize_multi', 'rt2d_heatmap_finalize', 'rt2d_cast_heatmap', 'rt2d_gain_heatmap', 'rt2d_gain_heatmap_rest', 'rt2d_rebound_loss']
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources and the C header: names the build a profile measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*'))) + [os.path.join(os.path.dirname(_HERE), 'include', 'rt2d.h')]
+    for path in files:
+        if os.path.isfile(path) and not path.endswith(('.o', '.so')):
+            h.update(os.path.basename(path).encode())
+            with open(path, 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_info():
+    """{source_sha256, git_head, git_dirty}: the hash is computed from the tree; the git fields come from the file written
+    next to the library when it was built here (there is no .git on the GPU box)."""
+    import json
+    info = {'source_sha256': source_hash(), 'git_head': None, 'git_dirty': None}
+    path = os.path.join(_HERE, 'BUILD_INFO.json')
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                old = json.load(f)
+            if old.get('source_sha256') == info['source_sha256']:
+                info.update(git_head=old.get('git_head'), git_dirty=old.get('git_dirty'))
+        except (OSError, ValueError):
+            pass
+    return info
+
+
+def _write_build_info():
+    import json
+    import subprocess
+    info = {'source_sha256': source_hash(), 'git_head': None, 'git_dirty': None}
+    root = os.path.dirname(_HERE)
+    try:
+        info['git_head'] = subprocess.check_output(['git', '-C', root, 'rev-parse', 'HEAD'], text=True, stderr=subprocess.DEVNULL).strip()
+        info['git_dirty'] = bool(subprocess.check_output(['git', '-C', root, 'status', '--porcelain', '--', 'ray-tracer_amd/csrc', 'include'],
+                                                         text=True, stderr=subprocess.DEVNULL).strip())
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    try:
+        with open(os.path.join(_HERE, 'BUILD_INFO.json'), 'w') as f:
+            json.dump(info, f)
+    except OSError:
+        pass
+
+
 def build(force=False, verbose=False):
     """Compile the HIP kernels for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     deps = SOURCES + HEADERS
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        _write_build_info()
         return SO_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',
@@ -33,6 +83,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    _write_build_info()
     return SO_PATH
 
 

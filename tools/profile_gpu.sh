@@ -15,6 +15,9 @@ shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# the build these passes measure (hash of the kernel sources; the git commit it was built at, if the library was built
+# in the development container): stamped into every summary by tools/summarize_profile.py
+python3 -c "import sys, json; sys.path.insert(0, '$REPO'); import rt2d_loader; rt = rt2d_loader.load(); print(json.dumps(rt._lib.build_info()))" > "$OUT/build.json"
 cd /tmp && export TMPDIR=/tmp
 BENCH="$REPO/bench.py --no-cpu $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $BENCH --steps 30 --warmup 3 --large-steps 3 > "$OUT/trace.log" 2>&1

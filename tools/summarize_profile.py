@@ -51,6 +51,12 @@ def main():
             grid = int(row['Grid_Size_X']) * int(row['Grid_Size_Y']) * int(row['Grid_Size_Z'])
             key = (short(row['Kernel_Name']), grid, int(row['Workgroup_Size_X']))
             groups[key].append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
+    # which build was measured: written on the GPU box next to the passes (tools/profile_gpu.sh)
+    build = None
+    bpath = os.path.join(src, 'build.json')
+    if os.path.exists(bpath):
+        with open(bpath) as f:
+            build = json.load(f)
     pmc = {}
     for which, sub, fname in (('FETCH_SIZE', 'fetch', 'f_counter_collection.csv'), ('WRITE_SIZE', 'write', 'w_counter_collection.csv')):
         path = os.path.join(src, sub, fname)
@@ -84,7 +90,7 @@ def main():
         w.writerows(rows)
     with open(os.path.join(dst, f'{tag}_traffic.json'), 'w') as f:
         json.dump(dict(units='bytes per launch; FETCH_SIZE [KiB] x 1024 x 2 (gfx950), WRITE_SIZE [KiB] x 1024',
-                       kernels=traffic), f, indent=1)
+                       build=build, kernels=traffic), f, indent=1)
     # optional passes: instruction mix and L2 atomics
     names = ('SQ_INSTS_VALU', 'SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64',
              'SQ_INSTS_VALU_TRANS_F64', 'SQ_INSTS_SALU', 'SQ_WAVES', 'SQ_INSTS_LDS', 'TCC_ATOMIC_sum', 'TCC_REQ_sum')
@@ -117,7 +123,7 @@ def main():
                     c['atomics_per_s'] = c['TCC_ATOMIC_sum'] / t
             out[f'{key[0]}|grid={key[1]}|wg={key[2]}'] = c
         with open(os.path.join(dst, f'{tag}_counters.json'), 'w') as f:
-            json.dump(dict(units='counter values per launch (mean over the launches of the pass)', kernels=out), f, indent=1)
+            json.dump(dict(units='counter values per launch (mean over the launches of the pass)', build=build, kernels=out), f, indent=1)
     for line in open(os.path.join(src, 'trace.log')):
         if line.startswith('{'):
             with open(os.path.join(dst, f'{tag}_bench.json'), 'w') as f:
