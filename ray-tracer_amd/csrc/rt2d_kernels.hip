@@ -1553,6 +1553,8 @@ struct HeatArgs {
     // several frequencies at once (rt2d_heatmap_accumulate_multi): map f is H + f * map_stride, its gains Gs[f]
     const double* const* Gs; int32_t n_freqs; int64_t map_stride;
     const int32_t* g_slot; int64_t g_room;          // optional: G in the compact form of GainArgs::g_slot (general kernel only)
+    int32_t group;                                  // general kernel: consecutive rays one workgroup bins, one after the other
+    int32_t acc_cap;                                // ... slots of the LDS table their deposits are summed in (0 = none), power of two
 };
 
 // Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
@@ -1764,6 +1766,13 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
     __shared__ int s_red[2];
     int32_t* s_cell = reinterpret_cast<int32_t*>(s_hash + a.cap);
+    // Neighbouring rays of the list visit mostly the same cells: a workgroup bins `group` consecutive rays one after the
+    // other and sums their deposits in an LDS table first (acc_cap slots: cell -> sum, two probes, a deposit that finds
+    // both taken goes to the map directly); one atomic per occupied slot reaches L2 when the group is done.
+    double* s_acc_val = reinterpret_cast<double*>(s_cell + a.cell_cap);
+    int32_t* s_acc_key = reinterpret_cast<int32_t*>(s_acc_val + a.acc_cap);
+    const bool use_acc = a.acc_cap > 0 && a.n_freqs == 0;
+    const uint32_t acc_mask = (uint32_t)a.acc_cap - 1;
     const int lane = threadIdx.x;
     const int64_t size = a.nx * a.nz;
     const uint32_t mask = (uint32_t)a.cap - 1;
@@ -1775,7 +1784,13 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
     // about the same time and a line is fetched once for the group instead of once per ray (grid: a multiple of 128).
     const int64_t b_xcd = blockIdx.x & 7, b_in = blockIdx.x >> 3;
     const int64_t first_item = ((b_in >> 4) * 8 + b_xcd) * 16 + (b_in & 15);
-    for (int64_t item = first_item; item < n_items; item += gridDim.x) {
+    const int64_t group = a.group > 1 ? a.group : 1;
+    for (int64_t item0 = first_item * group; item0 < n_items; item0 += (int64_t)gridDim.x * group) {
+      if (use_acc) {
+          for (int i = lane; i < a.acc_cap; i += HM_THREADS) { s_acc_key[i] = -1; s_acc_val[i] = 0.0; }
+          __syncthreads();
+      }
+      for (int64_t item = item0; item < item0 + group && item < n_items; ++item) {
         const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
         if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
         const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
@@ -1874,8 +1889,21 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                 }
                 if (a.n_freqs == 0) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (own[u] >= 0) atomicAdd(&a.H[own[u]], rt2d_heat_val(gv[u]));     // ray.py:317, simulation.py:129
+                    for (int u = 0; u < 8; ++u) {
+                        if (own[u] < 0) continue;
+                        const double v = rt2d_heat_val(gv[u]);                               // ray.py:317, simulation.py:129
+                        bool staged = false;
+                        if (use_acc) {
+                            const uint32_t h = rt2d_hash32((uint32_t)own[u] * 0x9e3779b1u);
+#pragma unroll
+                            for (int probe = 0; probe < 2 && !staged; ++probe) {
+                                const uint32_t slot = (h + probe) & acc_mask;
+                                const int32_t old = atomicCAS(&s_acc_key[slot], -1, own[u]);
+                                if (old == -1 || old == own[u]) { unsafeAtomicAdd(&s_acc_val[slot], v); staged = true; }
+                            }
+                        }
+                        if (!staged) atomicAdd(&a.H[own[u]], v);
+                    }
                 } else {
                     // several maps: the owning step of a cell is the same for every frequency, only the value differs
                     for (int f = 0; f < a.n_freqs; ++f) {
@@ -1889,6 +1917,12 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
             }
             __syncthreads();
         }
+      }
+      if (use_acc) {                                  // (every ray of the group ended on a barrier)
+          for (int i = lane; i < a.acc_cap; i += HM_THREADS)
+              if (s_acc_key[i] >= 0) atomicAdd(&a.H[s_acc_key[i]], s_acc_val[i]);
+          __syncthreads();
+      }
     }
 }
 
@@ -2525,14 +2559,31 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     const bool small_coords = res[0] < (1 << 20) && res[1] < (1 << 20) &&
                               (int64_t)shape[0] * res[0] < (1ll << 31) && (int64_t)shape[1] * res[1] < (1ll << 31);
     a.g_slot = g_slot; a.g_room = g_room;
+    // general kernel: a workgroup takes `group` consecutive rays of its list when there are rays enough to fill the chip
+    // that way, and sums their deposits in LDS before they go to the map (then 2048 cached cells per ray leave room for
+    // three workgroups per CU as before)
+    static const int group_env = getenv("RT2D_HM_GROUP") ? atoi(getenv("RT2D_HM_GROUP")) : 0;
+    auto launch_general = [&](int64_t items_est, int64_t items_max) -> int32_t {
+        int64_t group = group_env > 0 ? group_env : items_est / 4096;
+        group = group < 1 ? 1 : (group > 4 ? 4 : group);     // measured on the 37 000 turned-back rays of the 1M-ray C2 fan:
+        // 1 ray 1.64 ms / 29.6 M atomics, 4 rays 1.26 ms / 18.1 M, 8 rays 1.46 ms / 17.0 M (the table is full: with 4096 slots
+        // 11.6 M atomics but one workgroup less per CU and 2.7 ms) -- these rays are the ones that scatter, their
+        // neighbours share fewer cells than the rays of the tile kernel do
+        a.group = (int32_t)group;
+        static const int acc_env = getenv("RT2D_HM_ACC") ? atoi(getenv("RT2D_HM_ACC")) : 1024;
+        a.acc_cap = (group > 1 && n_freqs == 0) ? acc_env : 0;
+        if (a.acc_cap && a.cell_cap > 2048) a.cell_cap = 2048;
+        const int64_t groups = (items_max + group - 1) / group;
+        const int64_t blocks = groups < 16384 ? (groups + 127) / 128 * 128 : 16384;
+        const size_t lds = (size_t)a.cap * 8 + (size_t)a.cell_cap * 4 + (size_t)a.acc_cap * 12;
+        if (blocks > 0) hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(HM_THREADS), lds, stream, a);
+        HIP_OK(hipGetLastError());
+        return 0;
+    };
     if (rest_list) {
         // the caller's own list of rays ([0] = their number, [2 + k] = ray ids), all of them for the general kernel
         a.work = const_cast<int32_t*>(rest_list);
-        const int64_t blocks = n_rest < 16384 ? (n_rest + 127) / 128 * 128 : 16384;
-        if (blocks > 0)
-            hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(HM_THREADS), (size_t)a.cap * 8 + (size_t)a.cell_cap * 4, stream, a);
-        HIP_OK(hipGetLastError());
-        return 0;
+        return launch_general(n_rest, n_rest);
     }
     const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays && small_coords;
     if (work && !fast) HIP_OK(hipMemsetAsync(work, 0xff, sizeof(int32_t), stream));     // work[0] = -1: every ray went general
@@ -2556,11 +2607,9 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 1>), dim3(blocks), dim3(wpb * RT2D_WAVE), 0, stream, a);
         HIP_OK(hipGetLastError());
     }
-    // general kernel: everything (no workspace) or what the fast kernel queued; blocks stride over the items
-    const int64_t blocks = n < 16384 ? (n + 127) / 128 * 128 : 16384;
-    hipLaunchKernelGGL(rt2d_heatmap_kernel, dim3((unsigned)blocks), dim3(HM_THREADS), (size_t)a.cap * 8 + (size_t)a.cell_cap * 4, stream, a);
-    HIP_OK(hipGetLastError());
-    return 0;
+    // general kernel: everything (no workspace) or what the fast kernel queued (how many is only known on the device: a
+    // few per cent of the fan as a rule); blocks stride over the items
+    return launch_general(fast ? n / 32 : n, n);
 }
 }  // extern "C++"
 
