@@ -946,17 +946,18 @@ __global__ void rt2d_tile_len_kernel(const int32_t* n_pts, int64_t n, int64_t n_
     if (t == 0 && lane == 0) tile_off[0] = 0;
 }
 
-__global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     // one block of 1024
-    __shared__ int64_t s_part[1024];
+__global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     // one block (64 ... 1024 threads: a small fan
+    __shared__ int64_t s_part[1024];                                            // pays for one wave's barriers only)
     __shared__ int64_t s_carry;
+    const int B = blockDim.x;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (int64_t start = 0; start < n_tiles; start += 1024) {
+    for (int64_t start = 0; start < n_tiles; start += B) {
         int64_t i = start + threadIdx.x;
         int64_t v = (i < n_tiles) ? tile_off[i + 1] : 0;
         s_part[threadIdx.x] = v;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
+        for (int off = 1; off < B; off <<= 1) {
             int64_t add = (threadIdx.x >= off) ? s_part[threadIdx.x - off] : 0;
             __syncthreads();
             s_part[threadIdx.x] += add;
@@ -964,7 +965,7 @@ __global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     
         }
         if (i < n_tiles) tile_off[i + 1] = s_part[threadIdx.x] + s_carry;
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry += s_part[1023];
+        if (threadIdx.x == B - 1) s_carry += s_part[B - 1];
         __syncthreads();
     }
 }
@@ -2133,6 +2134,12 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
         int lanes = 1;
         while ((int64_t)lanes * n_cu < n) lanes *= 2;
         a.lanes = lanes;
+        // (experiment: the same rays per CU spread over more waves of fewer lanes, RT2D_CAST_LANES = lanes per wave)
+        static const int lanes_env = getenv("RT2D_CAST_LANES") ? atoi(getenv("RT2D_CAST_LANES")) : 0;
+        if (lanes_env >= 1 && lanes_env < lanes && (lanes_env & (lanes_env - 1)) == 0) {
+            block = (lanes / lanes_env) * RT2D_WAVE;
+            a.lanes = lanes_env;
+        }
     } else {
         // smallest workgroup with which all workgroups are resident at once (LDS decides how many fit on a CU); with the
         // small LDS footprint of the hybrid mode: two waves per workgroup, ten workgroups per CU
@@ -2299,7 +2306,7 @@ int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int
         const int wpb = 4;
         hipLaunchKernelGGL(rt2d_tile_len_kernel, dim3((unsigned)((n_tiles + wpb - 1) / wpb)), dim3(wpb * RT2D_WAVE), 0, stream,
                            n_pts, n, n_tiles, tile_off);
-        hipLaunchKernelGGL(rt2d_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, tile_off);
+        hipLaunchKernelGGL(rt2d_tile_scan_kernel, dim3(1), dim3(n_tiles <= 64 ? 64 : n_tiles <= 256 ? 256 : 1024), 0, stream, n_tiles, tile_off);
         HIP_OK(hipGetLastError());
     }
     if (total_out) {
