@@ -1103,8 +1103,10 @@ class RayPack2D:
 
     def _sole_pending_fan(self):
         """The fan, if this pack is exactly one whole fan that has not been folded in yet (else None)."""
-        if len(self._pending) == 1 and self._pending[0][1] is None and self._n_rays == 0 and not len(self._rays):
-            return self._pending[0][0]
+        if len(self._pending) == 1 and self._n_rays == 0 and not len(self._rays):
+            fan, indices = self._pending[0]
+            if indices is None or (getattr(fan, '_whole_in_pack', False) and len(indices) == fan.n):
+                return fan
         return None
 
     rays = property(lambda self: (self._resolve(), self._rays)[1])
@@ -1142,10 +1144,14 @@ class RayPack2D:
     def add_fan(self, fan, indices=None):
         """Add rays of a fan (all, or the given indices), skipping errored rays and angles already present.  The fan is
         folded in when the pack is first looked at."""
-        self._pending.append((fan, None if indices is None else np.asarray(indices, dtype=np.int64)))
+        if indices is not None and not hasattr(indices, 'data_ptr'):         # (a device tensor is fetched when the pack is resolved)
+            indices = np.asarray(indices, dtype=np.int64)
+        self._pending.append((fan, indices))
         self._maps = None
 
     def _add_fan_now(self, fan, indices=None):
+        if indices is not None and hasattr(indices, 'data_ptr'):
+            indices = indices.cpu().numpy()
         ang = np.asarray(fan.angles, dtype=np.float64)
         status = fan.host('status')
         idx_all = np.arange(fan.n) if indices is None else np.asarray(indices, dtype=np.int64)
