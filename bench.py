@@ -591,9 +591,9 @@ def main():
         result['large_fan_fused'] = {
             'rays': nL, 'ray_steps': sf, 'value': sf * args.large_steps / dtf, 'unit': 'ray-steps/s',
             's_per_heatmap': dtf / args.large_steps,
-            'path': 'Simulation2D.cast(store=False) + heatmap(): lazy fan, chunked cast-with-trajectories -> bin -> drop on two '
-                    'streams (no counting pass)',
-            'chunk_rays': rays_mod.CHUNK_RAYS, 'passes': fan_f.passes,
+            'path': 'Simulation2D.cast(store=False) + heatmap(): lazy fan, cast-with-trajectories -> one-pass gain+bin -> drop, in chunks '
+                    'of as many rays as a third of the free HBM holds (no counting pass, no gain array)',
+            'chunk_rays': fan_f._chunk_rays(), 'passes': fan_f.passes,
             'rays_binned_by_the_general_kernel': int(fan_f.last_slow_rays),
             'max_abs_diff_vs_stored_map': float((hm_f - hm_l).abs().max().item())}
         del fan_f, hm_f

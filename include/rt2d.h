@@ -251,13 +251,24 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
  * value 2 (turned back, left the map, too steep: RayFan.fused_mask says which) only get their gain computed by it, into
  * a COMPACT array -- ray r at G_rest[g_slot[r] * g_room + step], g_room >= its points -- and are then binned by the
  * general one-ray-per-workgroup kernel ("last write wins" by an LDS hash, simulation.py:120-131), which reads that array.
- * rest_list: int32 device array, [0] = n_rest, [1] unused, [2 + k] = the k-th such ray; n_rest: the same count on the host.
+ * rest_list: int32 device array, [0] = n_rest, [1] unused, [2 + k] = the k-th such ray; n_rest: that count on the host, or an
+ * upper bound of it when the list was made on the device (rt2d_classify_rays); a listed ray with g_slot < 0 is skipped.
  * No gain array of the layout's size exists at any time.  Same map as rt2d_gain + rt2d_heatmap_accumulate. */
 int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                                const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                                const int32_t* res, const int32_t* shape, double* H,
                                const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
                                int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream);
+
+/* The ray_mask, rest_list and g_slot arguments of rt2d_gain_heatmap_rest, made on the device from a cast's per-ray results
+ * (no reference counterpart: RayFan.fused_mask, which it restates, needs the host to wait for the cast): m[r] = 1 / 2 / 0 as
+ * described there for the rays with status 0 (and ray_mask != 0 when one is given); the rays of value 2 are appended to
+ * rest_list ([0] = count, [2 + k] = ray; n + 2 ints) and get row g_slot[r] = k of a compact gain array of `rows` rows.  A
+ * ray beyond the last row gets g_slot = -1, is left out by both kernels, and *overflow (a device double, e.g. a spare
+ * word behind the fan's summary) is set to 1: the caller reads it with the summary and bins the fan another way. */
+int32_t rt2d_classify_rays(const int32_t* status, const uint8_t* monotone, const double* range, const double* slope_max,
+                           const uint8_t* ray_mask, int64_t n, const int32_t* res, const int32_t* shape, int64_t rows,
+                           uint8_t* m, int32_t* g_slot, int32_t* rest_list, double* overflow, void* stream);
 
 /* Distance to a target from stored trajectories (reference: ray.py:282-287). dist: device, n. */
 int32_t rt2d_dist(const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts, int64_t n,

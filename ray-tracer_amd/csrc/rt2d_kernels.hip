@@ -141,6 +141,10 @@ __device__ __forceinline__ double rt2d_heat_val(double g) {
 }
 
 
+// Wave votes straight from the compare's lane mask (the library forms go through a 0/1 register and a second compare)
+__device__ __forceinline__ bool rt2d_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool rt2d_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 // Adds val into H[cell] for every lane that calls with want = true.  Neighbouring lanes are neighbouring angles and
 // mostly sit in the same cell at the same step: runs of adjacent depositing lanes with equal cells are summed first
 // (segmented inclusive scan) and the last lane of each run issues ONE atomic.  Callable from divergent code: only the
@@ -275,6 +279,19 @@ struct RayBinner {
     __device__ __forceinline__ void point(const BinTarget& t, double x, double z, double g, int lane, bool live = true) {
         int ix, iz;
         const bool in_map = rt2d_cell_i32(t.geo, x, z, ix, iz) && (unsigned)ix < (unsigned)t.nx && (unsigned)iz < (unsigned)t.nz;
+        if (FULL && t.dbg == 0) {
+            // The common step of a sorted fan: every lane that bins a point enters a column further on and remembers no row
+            // of the column it leaves (dx_max = the cell width: a new column every step).  Then nothing of the slot and row
+            // bookkeeping below applies: the cell left is deposited as it is and the new cell becomes the current one.
+            const bool binning = live & ok;
+            if (rt2d_all(!binning | (in_map & (ix > cur_ix) & (occ == 0u)))) {
+                double v = 0.0;
+                if (binning) v = t.sign * rt2d_heat_val(cur_g);                  // ray.py:317, simulation.py:129
+                rt2d_deposit_full(t.H, binning, cur_ix * t.nz + cur_iz, v, lane);
+                if (binning) { cur_ix = ix; cur_iz = iz; col_lo = iz; col_hi = iz; cur_g = g; }
+                return;
+            }
+        }
         if (live && ok && (!in_map || ix < cur_ix)) { ok = false; violated = true; }
         const bool newcol = live && ok && ix != cur_ix;
         const bool newrow = live && ok && !newcol && iz != cur_iz;
@@ -347,9 +364,6 @@ __device__ __forceinline__ double rt2d_div_by_const(double a, double b, double y
     return fma(r1, y, q1);
 }
 
-// Wave votes straight from the compare's lane mask (the library forms go through a 0/1 register and a second compare)
-__device__ __forceinline__ bool rt2d_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-__device__ __forceinline__ bool rt2d_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 
 // a / 1000 of the gain integrand (ray.py:346): five FMAs instead of the 13-instruction division (with its quarter-rate
 // reciprocal) in every (point, frequency) of the gain loops; outside the range the identity is tested on, divide.
@@ -1383,6 +1397,41 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
 }
 
 
+// Which kernel bins which ray of a fan for the one-pass heat map (RayFan.fused_mask, evaluated on the device so that the
+// host need not wait for the cast): m[r] = 1 for the rays rt2d_gain_heatmap_kernel can bin (no error, x never decreases,
+// bounding box inside the map, at most 8 rows per column by the slope bound), 2 for the other error-free rays, 0 for the
+// rest.  The rays of value 2 are appended to `list` ([0] = their count, [2 + k] = ray; a wave's rays stay adjacent) and
+// get row k of the compact gain array (g_slot[r] = k); beyond `rows` rows there is none (g_slot = -1, *overflow = 1: the
+// map will be incomplete and the caller, who reads the flag with the fan's summary, builds it again another way).
+__global__ void __launch_bounds__(256) rt2d_classify_kernel(const int32_t* status, const uint8_t* monotone, const double* range,
+                                                            const double* slope_max, const uint8_t* ray_mask, int64_t n,
+                                                            double res_x, double res_z, double nx, double nz, int64_t rows,
+                                                            uint8_t* m, int32_t* g_slot, int32_t* list, double* overflow) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool has = r < n;
+    const int64_t q = has ? r : n - 1;
+    const bool sel = has && status[q] == 0 && (!ray_mask || ray_mask[q] != 0);
+    const bool ok = sel && monotone[q] != 0 && range[q] > -1 && range[3 * n + q] < 1
+                 && floor(trunc(range[2 * n + q]) / res_x) < nx && floor(-trunc(range[n + q]) / res_z) < nz
+                 && floor(slope_max[q] * (res_x / res_z)) + 2 <= 8;
+    const bool rest = sel && !ok;
+    const unsigned long long votes = __builtin_amdgcn_ballot_w64(rest);
+    int base = 0;
+    if (votes != 0ull) {
+        const int first = (int)__builtin_ctzll(votes);
+        if (lane == first) base = atomicAdd(&list[0], (int)__builtin_popcountll(votes));
+        base = __builtin_amdgcn_readlane(base, first);
+    }
+    if (rest) {
+        const int k = base + (int)__builtin_popcountll(votes & ((1ull << lane) - 1ull));
+        list[2 + k] = (int32_t)r;
+        g_slot[r] = k < rows ? k : -1;
+        if (k >= rows) *overflow = 1.0;
+    }
+    if (has) m[r] = ok ? 1 : (rest ? 2 : 0);
+}
+
 // Gain at ONE frequency and heat-map binning in one forward pass over stored trajectories: the gain of a point is used
 // the moment it exists and never written (rt2d_gain + rt2d_heatmap_accumulate move 8 B per point out and 24 B back in).
 // Same gain expressions as rt2d_gain_kernel, same binning as the fused stepping kernel (RayBinner).  ray_mask: 1 = bin
@@ -1391,6 +1440,7 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
 struct GainHeatArgs {
     GainArgs g; BinTarget bin; double freq;
     const uint8_t* ray_mask; uint8_t* irregular; unsigned long long* n_violations;
+    const int32_t* ray_list;       // optional: the rays of this launch ([0] = count, [2 + k] = ray), all of them gain-only (value 2)
 };
 
 template <bool LOSS>
@@ -1404,13 +1454,15 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
     // All 64 lanes of a wave stay in the point loop until the wave's longest ray has ended -- a lane without a ray, with
     // a masked ray or past its ray's end carries live = false and computes on stale values -- so that the deposits run
     // with every lane enabled (rt2d_deposit_full) and the loop has one wave-uniform exit.
-    const int64_t r_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t r_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b.ray_list) r_raw = r_raw < (int64_t)b.ray_list[0] ? (int64_t)b.ray_list[2 + r_raw] : a.n;
     const bool has = r_raw < a.n;
     const int64_t r = has ? r_raw : a.n - 1;
-    const uint8_t flags = !has ? (uint8_t)0 : (b.ray_mask ? b.ray_mask[r] : (uint8_t)1);
+    const uint8_t flags = !has ? (uint8_t)0 : b.ray_list ? (uint8_t)2 : (b.ray_mask ? b.ray_mask[r] : (uint8_t)1);
     const bool binme = (flags & 1) != 0;
     const DevTable& ab = a.env.absorb;
-    const int np = flags ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
+    // (a ray that is neither binned here nor has anywhere to put its gain has nothing to do in this launch)
+    const int np = (binme || (flags && (a.G != nullptr || a.G_end != nullptr))) ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
     if (!rt2d_any(np > 0)) return;
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
     const double fr = b.freq;
@@ -1425,9 +1477,11 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
     RayBinner binner;
     binner.start(b.bin, binme && np > 0, s_tab + a.env.gain_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, xp, zp, 0.0);
     // where this ray's gain goes when it is only computed here: its points of the tile layout, or its own row of a compact G
-    const int64_t g_base = a.g_slot ? (int64_t)a.g_slot[r] * a.g_room : base;
+    const int32_t g_row = a.g_slot ? a.g_slot[r] : 0;
+    const int64_t g_base = a.g_slot ? (int64_t)g_row * a.g_room : base;
     const int64_t g_step = a.g_slot ? 1 : RT2D_WAVE;
-    if (np > 0 && !binme && a.G) a.G[g_base] = 0.0;
+    const bool g_store = !binme && a.G != nullptr && g_row >= 0;
+    if (np > 0 && g_store) a.G[g_base] = 0.0;
     double xn = xp, zn = zp;
     if (np > 1) { xn = a.X[base + RT2D_WAVE]; zn = a.Z[base + RT2D_WAVE]; }
     for (int s = 1; rt2d_any(s < np); ++s) {
@@ -1457,11 +1511,11 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
         if (live) S += dG;                                                 // ray.py:347
         const double g = S + A;
         binner.point<true>(b.bin, x, z, g, lane, live);                    // (a ray that is not binned here has ok = false)
-        if (live && !binme && a.G) a.G[g_base + s * g_step] = g;
+        if (live && g_store) a.G[g_base + s * g_step] = g;
         xp = x; zp = z;
     }
     binner.finish<true>(b.bin, lane);
-    if (!flags) return;
+    if (!flags || np == 0) return;
     if (b.irregular) b.irregular[r] = binner.violated ? 1 : 0;
     if (binner.violated && b.n_violations) atomicAdd(b.n_violations, 1ull);
     if (a.G_end) a.G_end[r] = S + A;
@@ -1794,6 +1848,7 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
       for (int64_t item = item0; item < item0 + group && item < n_items; ++item) {
         const int64_t r = a.work ? (int64_t)a.work[2 + item] : item;
         if (!a.work && a.ray_mask && !a.ray_mask[r]) continue;
+        if (a.g_slot && a.g_slot[r] < 0) continue;            // (no row of the compact gain array: rt2d_classify_kernel flagged it)
         const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
         const int64_t base = a.tile_off[r >> 6] + (r & 63);
         const bool cached = np <= a.cell_cap;
@@ -2443,7 +2498,8 @@ static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* 
                           const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                           const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,
                           uint8_t* irregular, int64_t* n_violations, double* loss_ws, void* stream,
-                          const int32_t* g_slot, int64_t g_room) {
+                          const int32_t* g_slot, int64_t g_room,
+                          const int32_t* ray_list = nullptr, int64_t n_list = 0, bool loss_ready = false) {
     if (!env || !X || !Z || !tile_off || !n_pts || !reb || !res || !shape || !H) return fail("rt2d_gain_heatmap: null argument");
     if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
         return fail("rt2d_gain_heatmap: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
@@ -2461,20 +2517,24 @@ static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* 
     b.bin = make_bin_target(H, res, shape, 1.0);
     b.freq = freq; b.ray_mask = ray_mask; b.irregular = irregular; b.n_violations = (unsigned long long*)n_violations;
     a.g_slot = g_slot; a.g_room = g_room;
+    b.ray_list = ray_list;
+    const int64_t n_launch = ray_list ? n_list : n;          // threads with a ray (list mode: an upper bound, the count is in the list)
     static const int block_env = getenv("RT2D_GH_BLOCK") ? atoi(getenv("RT2D_GH_BLOCK")) : 0;       // development knob
     // big fans: 3 workgroups of 4 waves per CU (with 8 waves a CU holds one workgroup: 2 waves per SIMD)
-    const int block = (block_env >= 64 && block_env <= 512) ? block_env / 64 * 64 : (n <= 64 * 512) ? 64 : 256;
+    const int block = (block_env >= 64 && block_env <= 512) ? block_env / 64 * 64 : (n_launch <= 64 * 512) ? 64 : 256;
     const size_t lds = ((size_t)env->dev.gain_doubles + (size_t)(block / RT2D_WAVE) * 8 * RT2D_WAVE) * sizeof(double);
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain_heatmap: absorption tables do not fit in LDS");
     void (*kern)(const GainHeatArgs) = rt2d_gain_heatmap_kernel<false>;
     if (loss_ws && rebound_cap > 0) {
         const int64_t pairs = n * rebound_cap;
-        hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, (hipStream_t)stream, a, loss_ws, freq);
+        if (!loss_ready)
+            hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, (hipStream_t)stream, a, loss_ws, freq);
         a.loss = loss_ws;
         kern = rt2d_gain_heatmap_kernel<true>;
     }
     ALLOW_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((n + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
+    if (n_launch > 0)
+        hipLaunchKernelGGL(kern, dim3((unsigned)((n_launch + block - 1) / block)), dim3(block), lds, (hipStream_t)stream, b);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -2672,6 +2732,28 @@ int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const do
     return heatmap_accumulate_impl(X, Z, nullptr, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream, Gs, n_freqs);
 }
 
+// the library's own second stream per device (rt2d_gain_heatmap_rest), made on first use and kept
+struct RestSide { hipStream_t stream; hipEvent_t ready, done; };
+extern "C++" {
+static int32_t rest_side(RestSide** out) {
+    static std::mutex mu;
+    static RestSide side[RT2D_MAX_DEVICES];
+    static bool made[RT2D_MAX_DEVICES];
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= RT2D_MAX_DEVICES) return fail("rt2d_gain_heatmap_rest: device %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!made[dev]) {
+        HIP_OK(hipStreamCreateWithFlags(&side[dev].stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&side[dev].ready, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&side[dev].done, hipEventDisableTiming));
+        made[dev] = true;
+    }
+    *out = &side[dev];
+    return 0;
+}
+}
+
 int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                                const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                                const int32_t* res, const int32_t* shape, double* H,
@@ -2679,12 +2761,66 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
                                int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream) {
     if (n_rest < 0 || (n_rest > 0 && (!rest_list || !g_slot || !G_rest || g_room <= 0)))
         return fail("rt2d_gain_heatmap_rest: rest_list, g_slot, G_rest and g_room describe the rays of ray_mask value 2");
-    int32_t rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
-                                   n_rest > 0 ? G_rest : nullptr, nullptr, nullptr, n_violations, loss_ws, stream,
-                                   n_rest > 0 ? g_slot : nullptr, g_room);
-    if (rc || n_rest == 0) return rc;
-    return heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, (hipStream_t)stream,
-                                   nullptr, 0, rest_list, n_rest, g_slot, g_room);
+    static const bool side_on = !(getenv("RT2D_REST_SIDE_STREAM") && atoi(getenv("RT2D_REST_SIDE_STREAM")) == 0);
+    if (n_rest == 0 || !side_on || !(loss_ws && rebound_cap > 0)) {
+        // one stream: the pass writes the side rays' gain, the general kernel follows it
+        int32_t rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
+                                       n_rest > 0 ? G_rest : nullptr, nullptr, nullptr, n_violations, loss_ws, stream,
+                                       n_rest > 0 ? g_slot : nullptr, g_room);
+        if (rc || n_rest == 0) return rc;
+        return heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, (hipStream_t)stream,
+                                       nullptr, 0, rest_list, n_rest, g_slot, g_room);
+    }
+    // Two streams: the side rays are few (a few per cent) and their chain -- gain of the listed rays by the same kernel in
+    // list mode, then the general kernel -- is two short launches of long-lived waves; queued BEHIND the big pass they
+    // add their whole length to the map's time, beside it they disappear in it.  Both start when the rebound losses are
+    // there; the caller's stream waits for the side chain at the end.
+    RestSide* side = nullptr;
+    int32_t rc = rest_side(&side);
+    if (rc) return rc;
+    hipStream_t main = (hipStream_t)stream;
+    {   // rebound losses, once, on the caller's stream (the same launch gain_heatmap_impl would make)
+        GainArgs a; memset(&a, 0, sizeof a);
+        a.env = env->dev; a.blob = env->blob; a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
+        a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
+        a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1;
+        if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
+            return fail("rt2d_gain_heatmap_rest: the rebound log is required");
+        const int64_t pairs = n * rebound_cap;
+        if (pairs > 0)
+            hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, main, a, loss_ws, freq);
+        HIP_OK(hipGetLastError());
+    }
+    HIP_OK(hipEventRecord(side->ready, main));
+    HIP_OK(hipStreamWaitEvent(side->stream, side->ready, 0));
+    rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
+                           G_rest, nullptr, nullptr, nullptr, loss_ws, side->stream, g_slot, g_room, rest_list, n_rest, true);
+    if (!rc) rc = heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, side->stream,
+                                          nullptr, 0, rest_list, n_rest, g_slot, g_room);
+    if (!rc) rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
+                                    nullptr, nullptr, nullptr, n_violations, loss_ws, stream, nullptr, 0, nullptr, 0, true);
+    // (whatever happened above, the caller's stream must not run ahead of work already queued on the side stream)
+    (void)hipEventRecord(side->done, side->stream);
+    (void)hipStreamWaitEvent(main, side->done, 0);
+    return rc;
+}
+
+int32_t rt2d_classify_rays(const int32_t* status, const uint8_t* monotone, const double* range, const double* slope_max,
+                           const uint8_t* ray_mask, int64_t n, const int32_t* res, const int32_t* shape, int64_t rows,
+                           uint8_t* m, int32_t* g_slot, int32_t* rest_list, double* overflow, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!status || !monotone || !range || !slope_max || !res || !shape || !m || !g_slot || !rest_list || !overflow)
+        return fail("rt2d_classify_rays: null argument");
+    if (n < 0 || rows < 0) return fail("rt2d_classify_rays: negative count");
+    if (res[0] <= 0 || res[1] <= 0 || shape[0] <= 0 || shape[1] <= 0) return fail("rt2d_classify_rays: bad resolution or shape");
+    if (n > 0x7fffffff - 2) return fail("rt2d_classify_rays: too many rays for one list");
+    HIP_OK(hipMemsetAsync(rest_list, 0, 2 * sizeof(int32_t), stream));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rt2d_classify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, status, monotone, range,
+                       slope_max, ray_mask, n, (double)res[0], (double)res[1], (double)shape[0], (double)shape[1], rows,
+                       m, g_slot, rest_list, overflow);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int32_t rt2d_heatmap_finalize_multi(const double* H, const int32_t* shape, int32_t n_maps, double cutoff, double reduction_power,

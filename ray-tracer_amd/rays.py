@@ -22,6 +22,7 @@ from . import _lib
 from ._lib import STOP_REASONS, RAY_ERR_INTERP
 
 TILE = 64
+SUMMARY_LEN = 9                  # the 8 doubles of rt2d_fan_summary + one flag word (RayFan._queue_summary)
 _UNIFORM_LAYOUTS = {}            # (device, tiles, room) -> tile offsets of a uniform provisional layout (reused between casts)
 HEATMAP_FAST_MIN_RAYS = int(os.environ.get('RT2D_HEATMAP_FAST_MIN_RAYS', 6000))    # same switch as the library's
 SPECULATIVE_ROOM = 4096          # points per ray a speculative single-pass cast reserves
@@ -31,8 +32,10 @@ SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below
 # long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
 PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
 STREAM_MIN_RAYS = int(os.environ.get('RT2D_STREAM_MIN_RAYS', 1 << 19))    # fans from here on bin through the one-pass kernel
-CHUNK_RAYS = int(os.environ.get('RT2D_CHUNK_RAYS', 1 << 19))           # rays cast with trajectories at a time by the chunked heat map
+CHUNK_RAYS = int(os.environ.get('RT2D_CHUNK_RAYS', 0))               # rays cast with trajectories at a time by the chunked heat map;
+                                                                     # 0: as many as a third of the free HBM holds (RayFan._chunk_rays)
 CHUNKED_MIN_RAYS = int(os.environ.get('RT2D_CHUNKED_MIN_RAYS', 1 << 18))   # store=False fans from here on use it (smaller: fused kernel)
+ONEPASS_MIN_ROWS, ONEPASS_ROWS_DIV = 4096, 8      # rows of the compact gain array of a one-pass map queued without waiting: max(.., n / ..)
 CHUNK_STREAMS = int(os.environ.get('RT2D_CHUNK_STREAMS', 2))
 SIDE_STREAM = os.environ.get('RT2D_SIDE_STREAM', '1') != '0'      # side fans of the fused heat map on a second stream
 SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat map hands rays to the stored path
@@ -51,6 +54,13 @@ def _ptr(t):
 
 
 _SIDE_STREAMS = {}
+
+
+def _free_bytes(device):
+    """HBM this process can still allocate through torch: what the driver reports free plus what torch's caching
+    allocator holds without using it (after a big fan has been dropped that is most of the card)."""
+    torch = _torch()
+    return torch.cuda.mem_get_info(device)[0] + max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
 
 
 def _side_stream(device, which=0):
@@ -260,7 +270,7 @@ class RayFan:
             nrm = int(self.kw['n_rebounds_max'])
             layout_bytes = n_tiles * room * TILE * (24 if store_c else 16)
             fits = layout_bytes <= SPECULATIVE_BYTES or (layout_bytes <= PADDED_BYTES and
-                                                         layout_bytes * 1.6 <= torch.cuda.mem_get_info(dev)[0])
+                                                         layout_bytes * 1.6 <= _free_bytes(dev))
             if known_n_pts is not None:
                 self.n_pts.copy_(known_n_pts)        # point counts from an earlier cast of these rays: no counting pass
                 counted = True
@@ -319,7 +329,8 @@ class RayFan:
     def _queue_summary(self, tile_off_exact, stream):
         """rt2d_fan_summary of the finished cast, queued behind it; read by validate()."""
         torch = _torch()
-        self._summary_dev = torch.empty(8, dtype=torch.float64, device=self.device)
+        # (a ninth word behind the summary: "the one-pass heat map ran out of rows for its side rays", rt2d_classify_rays)
+        self._summary_dev = torch.zeros(SUMMARY_LEN, dtype=torch.float64, device=self.device)
         _lib.check(_lib.lib().rt2d_fan_summary(self.status.data_ptr(), self.range.data_ptr(), None, self.n,
                                                tile_off_exact.data_ptr(), self._summary_dev.data_ptr(), stream))
 
@@ -332,6 +343,7 @@ class RayFan:
             return False
         self._pending = False
         self._summary = self._summary_dev.tolist()
+        self._onepass_overflow = bool(self._summary[8])
         longest, log_full = int(self._summary[1]), bool(self._summary[2])
         if longest <= self._room * TILE and not log_full:
             return False
@@ -650,6 +662,19 @@ class RayFan:
         if side_stream is not main:
             main.wait_stream(side_stream)
 
+    def _chunk_rays(self):
+        """Rays per chunk of the chunked heat map: CHUNK_RAYS when set, else what a third of the free HBM (and at most
+        PADDED_BYTES) holds of provisional trajectories (16 B per point of room) -- a fan that fits is ONE chunk: the
+        memory that is there is used, a fan of any size still runs."""
+        if CHUNK_RAYS > 0:
+            return CHUNK_RAYS
+        torch = _torch()
+        room = min(int(self.kw['n_steps_max']) + 1, SPECULATIVE_ROOM)
+        budget = min(PADDED_BYTES, _free_bytes(self.device) // 3)
+        chunk = max(1 << 16, int(budget // (room * 16)) >> 16 << 16)
+        pieces = (self.n + chunk - 1) // chunk                     # equal pieces rather than full chunks and a small rest
+        return max(TILE, ((self.n + pieces - 1) // pieces + TILE - 1) // TILE * TILE)
+
     def heatmap_accumulate_chunked(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
         """Heat map of a fan that keeps no trajectories (store=False), CHUNK_RAYS rays at a time: the chunk is cast WITH
         trajectories, binned by the stored pipeline, and dropped again -- the trajectories in memory are never more than
@@ -663,31 +688,44 @@ class RayFan:
         first = bool(self.__dict__.get('_uncast'))
         n = self.n
         with torch.cuda.device(self.device):
+            chunk = self._chunk_rays()
+            adopt = first and n <= chunk              # one chunk: its per-ray results ARE the fan's (no copies, no second summary)
             if first:
                 self._uncast = False
-                self._cast(self._init_host, False, alloc_only=True)
+                if not adopt:
+                    self._cast(self._init_host, False, alloc_only=True)
             checks, slow, slows = [], 0, []
             # chunks alternate between two streams, each starting when the previous chunk's CAST is done: the long last
             # waves of one chunk's kernels (a chunk is one round of waves: its kernels last as long as its longest ray)
             # run beside the next chunk's
             main = torch.cuda.current_stream()
-            lanes = [main] + ([_side_stream(self.device, w) for w in range(CHUNK_STREAMS - 1)] if SIDE_STREAM and n > CHUNK_RAYS else [])
+            lanes = [main] + ([_side_stream(self.device, w) for w in range(CHUNK_STREAMS - 1)] if SIDE_STREAM and n > chunk else [])
             cast_done = None
-            for k, c0 in enumerate(range(0, n, CHUNK_RAYS)):
+            for k, c0 in enumerate(range(0, n, chunk)):
               lane_stream = lanes[k % len(lanes)]
               if cast_done is not None and lane_stream is not main:
                   lane_stream.wait_event(cast_done)
               with torch.cuda.stream(lane_stream):
-                c1 = min(n, c0 + CHUNK_RAYS)
+                c1 = min(n, c0 + chunk)
                 if first:
                     init = None if self._init_host is None else (np.asarray(self._init_host[0])[c0:c1], np.asarray(self._init_host[1])[c0:c1])
                     sub = RayFan(self.env, self.source, self.angles_dev[c0:c1], target=self.target, store=True, device=self.device,
                                  init=init, **dict(self.kw))
-                    for name in ('n_pts', 'stop_code', 'n_rebounds', 'status', 'monotone', 'slope_max', 'dist', 'step_target', 'T_target'):
-                        t = getattr(self, name)
-                        if t is not None:
-                            t[c0:c1].copy_(getattr(sub, name))
-                    self.range[:, c0:c1].copy_(sub.range)
+                    if adopt:
+                        for name in ('n_pts', 'stop_code', 'n_rebounds', 'status', 'monotone', 'slope_max', 'dist', 'step_target',
+                                     'T_target', 'range', '_init'):
+                            setattr(self, name, getattr(sub, name))
+                        self._scalars, self.rebound_cap, self.total, self.padded = None, 0, 0, False
+                        self.tile_off = self.X = self.Z = self.Cpt = None
+                        if not sub._pending:
+                            sub.validate()
+                        self._summary_dev = sub._summary_dev
+                    else:
+                        for name in ('n_pts', 'stop_code', 'n_rebounds', 'status', 'monotone', 'slope_max', 'dist', 'step_target', 'T_target'):
+                            t = getattr(self, name)
+                            if t is not None:
+                                t[c0:c1].copy_(getattr(sub, name))
+                        self.range[:, c0:c1].copy_(sub.range)
                     if sub._pending:
                         checks.append((sub._summary_dev, sub._room))
                 else:
@@ -695,9 +733,11 @@ class RayFan:
                     sub._need_store()
                 cast_done = lane_stream.record_event()
                 mask = (sub.status == 0) if ray_mask is None else ((sub.status == 0) & (ray_mask[c0:c1] != 0))
-                sub._pending = False                    # (checked below for all chunks at once)
+                # (a chunk's summary -- did it fit its provisional layout, did a one-pass map have rows enough for its side
+                # rays -- is checked below for all chunks at once: nothing here waits for the device)
                 sub.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask.to(torch.uint8), dropped=dropped,
-                                       stream=None if os.environ.get('RT2D_CHUNK_ONEPASS') else False)
+                                       defer=first and sub._pending)
+                sub._pending = False
                 w = getattr(sub, '_last_slow', 0)           # an int, or the work list of rt2d_heatmap_accumulate ([0] < 0: every ray)
                 slows.append(w if isinstance(w, int) else torch.where(w[0] < 0, torch.full_like(w[0], sub.n), w[0]))
                 del sub
@@ -708,22 +748,23 @@ class RayFan:
             self.last_fused_violations = torch.zeros(1, dtype=torch.int64, device=self.device)
             self._last_slow = slow if isinstance(slow, int) else slow.reshape(1)
             if first:
-                stream = torch.cuda.current_stream().cuda_stream
-                n_tiles = (n + TILE - 1) // TILE
-                exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=self.device)
-                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
-                self._queue_summary(exact, stream)
+                if not adopt:
+                    stream = torch.cuda.current_stream().cuda_stream
+                    n_tiles = (n + TILE - 1) // TILE
+                    exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=self.device)
+                    _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
+                    self._queue_summary(exact, stream)
                 self.passes = 'chunked'
                 # -- the one read: every chunk's summary and the fan's own --
                 got = torch.cat([c for c, _ in checks] + [self._summary_dev]).tolist()
                 for k, (_, room) in enumerate(checks):
-                    if int(got[8 * k + 1]) > room * TILE or bool(got[8 * k + 2]):
+                    if int(got[SUMMARY_LEN * k + 1]) > room * TILE or bool(got[SUMMARY_LEN * k + 2]) or bool(got[SUMMARY_LEN * k + 8]):
                         self._cast(self._init_host, False)          # cast the ordinary way; the caller starts over
                         return False
-                self._summary = got[-8:]
+                self._summary = got[-SUMMARY_LEN:]
         return True
 
-    def heatmap_accumulate_stream(self, H, res, shape, freq=1, ray_mask=None, dropped=None):
+    def heatmap_accumulate_stream(self, H, res, shape, freq=1, ray_mask=None, dropped=None, defer=False):
         """Gain and binning in ONE forward pass over the stored trajectories (rt2d_gain_heatmap_rest): no gain array of the
         layout's size exists.  The rays that pass cannot bin (fused_mask: turned back, left the map, too steep for its
         eight row slots) only get their gain from it, into one row each of a compact array, and the general kernel bins
@@ -732,7 +773,37 @@ class RayFan:
         torch = _torch()
         L = _lib.lib()
         with torch.cuda.device(self.device):
+            if defer and self._pending and self.padded:
+                # Queued behind a single-pass cast whose summary has not been read: the host knows neither the point
+                # counts nor which rays go to the general kernel.  rt2d_classify_rays sorts the rays out on the device and
+                # deals the side rays rows of a compact gain array sized by bounds (a row = the room of the provisional
+                # layout, n / 8 rows); "ran out of rows" lands in the word behind the fan's summary, and the caller --
+                # who reads the summary anyway (validate) -- then bins the fan again with known sizes (defer=False).
+                stream = torch.cuda.current_stream().cuda_stream
+                rows, g_room = max(ONEPASS_MIN_ROWS, self.n // ONEPASS_ROWS_DIV), int(self._room)
+                m = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+                slot = torch.empty(self.n, dtype=torch.int32, device=self.device)
+                rest_list = torch.empty(self.n + 2, dtype=torch.int32, device=self.device)
+                G_rest = torch.empty(rows * g_room, dtype=torch.float64, device=self.device)
+                viol = torch.zeros(1, dtype=torch.int64, device=self.device)
+                res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
+                shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+                _lib.check(L.rt2d_classify_rays(self.status.data_ptr(), self.monotone.data_ptr(), self.range.data_ptr(),
+                                                self.slope_max.data_ptr(), _ptr(ray_mask), self.n, res_c, shape_c, rows,
+                                                m.data_ptr(), slot.data_ptr(), rest_list.data_ptr(),
+                                                self._summary_dev[8:].data_ptr(), stream))
+                ws_elems = self.rebound_cap * self.n
+                loss_ws = torch.empty(ws_elems, dtype=torch.float64, device=self.device) if 0 < ws_elems * 8 <= LOSS_WS_BYTES else None
+                _lib.check(L.rt2d_gain_heatmap_rest(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
+                                                    self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap,
+                                                    self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(),
+                                                    rest_list.data_ptr(), rows, slot.data_ptr(), g_room, G_rest.data_ptr(),
+                                                    _ptr(dropped), viol.data_ptr(), _ptr(loss_ws), stream))
+                self._last_slow = rest_list            # ([0] = the number of side rays: read on demand)
+                self.last_fused_violations = viol
+                return
             self.validate()                              # the masks below need the final cast
+            self._onepass_overflow = False
             stream = torch.cuda.current_stream().cuda_stream
             sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
             m = self.fused_mask(res, shape, ray_mask)
@@ -794,7 +865,7 @@ class RayFan:
     def last_slow_rays(self, v):
         self._last_slow = int(v)
 
-    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True, stream=None):
+    def heatmap_accumulate(self, H, res, shape, freq=1, ray_mask=None, dropped=None, fast=True, hint=True, stream=None, defer=False):
         """Adds this fan's rays (or those with ray_mask != 0, a device uint8 tensor of n) into H (nx*nz, device f64).
         fast=False forces the general one-wave-per-ray kernel for every ray (used by the tests).
         stream=True: gain + binning in one pass (heatmap_accumulate_stream): the gain array (8 B per point) is never
@@ -816,7 +887,7 @@ class RayFan:
         if stream is None:
             stream = fast and freq not in self.G and self.n >= STREAM_MIN_RAYS
         if stream:
-            return self.heatmap_accumulate_stream(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
+            return self.heatmap_accumulate_stream(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped, defer=defer)
         torch = _torch()
         L = _lib.lib()
         if freq not in self.G:

@@ -154,7 +154,8 @@ class Simulation2D:
             else:
                 mask = (fan.status == 0).to(torch.uint8)
                 fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
-                                       fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
+                                       fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None),
+                                       defer=True)
             out_b = None
             if finalize:
                 out_b = torch.empty((int(shape_b[1]), int(shape_b[0])), dtype=torch.float64, device=device)
@@ -164,8 +165,9 @@ class Simulation2D:
                                                             float(kwargs.get('reduction_power', .5)), out_b.data_ptr(),
                                                             scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
             # -- the one read --
-            if fan.validate():
-                return None                                   # cast again with counted sizes: start over
+            if fan.validate() or getattr(fan, '_onepass_overflow', False):
+                return None                                   # cast again with counted sizes, or a one-pass map without rows
+                                                              # enough for its side rays: start over
             if distinct is not None and not bool(distinct.item()):
                 return None                                   # repeated angles: the pack keeps the first of each
         summ = fan._summary

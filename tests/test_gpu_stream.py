@@ -47,3 +47,40 @@ def test_stream_large_fan_padded_layout(rt):
     assert fan.passes == 'padded' and viol == 0
     assert np.array_equal(Hs == 0, Hr == 0)
     assert (np.abs(Hs - Hr)[Hr != 0] / Hr[Hr != 0]).max() < 1e-12
+
+
+def test_one_pass_map_queued_without_waiting_for_the_cast(rt, monkeypatch):
+    """Simulation2D.heatmap on a big stored fan queues the one-pass map behind the cast without reading anything back: the
+    rays are sorted out on the device (rt2d_classify_rays against RayFan.fused_mask), the side rays get rows of a compact
+    gain array sized by a bound; with too few rows the flag behind the fan's summary sends the map through the waiting
+    path.  Same map three ways."""
+    import torch
+    from ray_tracer_amd import rays
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    kw = common.prop_kwargs(g)
+    monkeypatch.setattr(rays, 'STREAM_MIN_RAYS', 100)
+
+    def one(**hk):
+        sim = rt.Simulation2D(env, g['fan_source'])
+        fan = sim.cast(g['fan_angles'], **kw)
+        pending = fan._pending
+        H, _ = sim.heatmap_full(resolution=[50, 25], **hk)
+        return fan, pending, H.cpu().numpy()
+
+    fan_a, _, Ha = one(stream=False)                      # three kernels
+    fan_b, pending, Hb = one()                            # one pass, queued without waiting
+    assert pending and not fan_b._onepass_overflow and fan_b.G == {}
+    n_side = fan_b.last_slow_rays
+    assert 0 < n_side < fan_b.n // 4
+    # the device classification is fused_mask
+    m_host = fan_b.fused_mask([50, 25], Hb.shape, (fan_b.status == 0).to(torch.uint8))
+    assert n_side == int(((fan_b.status == 0) & (m_host == 0)).sum().item())
+    monkeypatch.setattr(rays, 'ONEPASS_MIN_ROWS', 1)
+    monkeypatch.setattr(rays, 'ONEPASS_ROWS_DIV', 10 ** 9)
+    fan_c, _, Hc = one()                                  # one row for all side rays: overflow -> the waiting path
+    assert fan_c.last_slow_rays == n_side
+    for Hx in (Hb, Hc):
+        assert Hx.shape == Ha.shape and np.array_equal(Hx == 0, Ha == 0)
+        both = np.isfinite(Ha) & (Ha != 0)
+        assert (np.abs(Hx - Ha)[both] / np.abs(Ha[both])).max() < 1e-12
