@@ -471,6 +471,38 @@ __device__ __forceinline__ double rt2d_alpha(const double* rec, double d, double
     return alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
 }
 
+// The same quantities for the one-pass heat map, whose gain is never stored and only has to keep the map within its
+// 1e-12: FMA Horner, quotients and the square root to one ulp without the IEEE sequence's scaling and fix-up (the operands
+// are squares of table values plus (f/1000)^2 and squared distances in metres: no denormals, no overflow).  About 30
+// vector instructions fewer per point than the exact forms above, which every kernel that STORES a gain keeps.
+__device__ __forceinline__ double rt2d_div_fast(double n, double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0); y = fma(y, e, y);
+    e = fma(-d, y, 1.0); y = fma(y, e, y);
+    const double q = n * y;
+    return fma(fma(-d, q, n), y, q);
+}
+__device__ __forceinline__ double rt2d_sqrt_fast(double a) {           // a >= 0
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, a), h, g);
+    g = fma(fma(-g, g, a), h, g);
+    return a > 0.0 ? g : 0.0;
+}
+__device__ __forceinline__ double rt2d_quad_fma(const double* r, double d, int k) {
+    return fma(fma(r[1 + 3 * k], d, r[2 + 3 * k]), d, r[3 + 3 * k]);
+}
+__device__ __forceinline__ double rt2d_alpha_fast(const double* rec, double d, double ff) {
+    const double f1 = rt2d_quad_fma(rec, d, 0), f2 = rt2d_quad_fma(rec, d, 1);
+    const double A2 = rt2d_quad_fma(rec, d, 2), E1 = rt2d_quad_fma(rec, d, 3);
+    const double E2 = rt2d_quad_fma(rec, d, 4), E3 = rt2d_quad_fma(rec, d, 5);
+    const double alpha_1 = rt2d_div_fast(k_A1 * (f1 * ff), fma(f1, f1, ff));
+    const double alpha_2 = rt2d_div_fast(A2 * (f2 * ff), fma(f2, f2, ff));
+    return fma(alpha_1, E1, fma(alpha_2, E2, (k_A3 * ff) * E3));
+}
+
 // Rarely used launch data (rebound branch, final stores) is parked in LDS instead of scalar registers: the hot
 // loop alone needs ~90 SGPRs of table descriptors and bounds, and everything beyond the budget would be spilled
 // to v_writelane/v_readlane pairs inside the loop.
@@ -1441,11 +1473,14 @@ struct GainHeatArgs {
     GainArgs g; BinTarget bin; double freq;
     const uint8_t* ray_mask; uint8_t* irregular; unsigned long long* n_violations;
     const int32_t* ray_list;       // optional: the rays of this launch ([0] = count, [2 + k] = ray), all of them gain-only (value 2)
+    int32_t exact;                 // 1: never the fast forms of the gain (RT2D_GH_EXACT=1, tests)
 };
 
-template <bool LOSS>
-__global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(const GainHeatArgs b) {
+template <bool LOSS, bool FAST = false>
+__global__ void __launch_bounds__(512, FAST ? 3 : LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(const GainHeatArgs b) {
     const GainArgs& a = b.g;
+    // FAST: this launch only bins (no gain is stored, none asked for as a per-ray result): the fast forms of the gain
+    // (rt2d_alpha_fast).  A gain that leaves the kernel is the gain rt2d_gain gives (exact forms).
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
     __syncthreads();
@@ -1490,7 +1525,7 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
         const double x = xn, z = zn;
         if (s + 1 < np) { xn = a.X[o + RT2D_WAVE]; zn = a.Z[o + RT2D_WAVE]; }   // next point in flight during this step
         double ddx = x - xp, ddz = z - zp;
-        double dL = sqrt(ddx * ddx + ddz * ddz);
+        const double dL = FAST ? rt2d_sqrt_fast(fma(ddx, ddx, ddz * ddz)) : sqrt(ddx * ddx + ddz * ddz);
         double rec[20];
         rt2d_lookup<19>(tab, ab, zp, rec);                                  // factors at the START of the segment, ray.py:346
         while (live && s >= next_reb_at) {                                  // ray.py:350-362
@@ -1507,7 +1542,15 @@ __global__ void __launch_bounds__(512, LOSS ? 4 : 2) rt2d_gain_heatmap_kernel(co
             ++next_reb;
             next_reb_at = (next_reb < nreb) ? a.reb_step[(int64_t)next_reb * a.n + r] + 1 : 0x7fffffff;
         }
-        double dG = rt2d_div_1000(-1 * rt2d_alpha(rec, zp - rec[0], ff)) * dL;      // ray.py:346
+        // ray.py:346; FAST: alpha / 1000 as a product with one correction step
+        double dG;
+        if (FAST) {
+            const double al = -rt2d_alpha_fast(rec, zp - rec[0], ff);
+            const double q = al * 0.001;
+            dG = fma(fma(-q, 1000.0, al), 0.001, q) * dL;
+        } else {
+            dG = rt2d_div_1000(-1 * rt2d_alpha(rec, zp - rec[0], ff)) * dL;
+        }
         if (live) S += dG;                                                 // ray.py:347
         const double g = S + A;
         binner.point<true>(b.bin, x, z, g, lane, live);                    // (a ray that is not binned here has ok = false)
@@ -2518,6 +2561,8 @@ static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* 
     b.freq = freq; b.ray_mask = ray_mask; b.irregular = irregular; b.n_violations = (unsigned long long*)n_violations;
     a.g_slot = g_slot; a.g_room = g_room;
     b.ray_list = ray_list;
+    static const int exact_env = getenv("RT2D_GH_EXACT") ? atoi(getenv("RT2D_GH_EXACT")) : 0;
+    b.exact = exact_env;
     const int64_t n_launch = ray_list ? n_list : n;          // threads with a ray (list mode: an upper bound, the count is in the list)
     static const int block_env = getenv("RT2D_GH_BLOCK") ? atoi(getenv("RT2D_GH_BLOCK")) : 0;       // development knob
     // big fans: 3 workgroups of 4 waves per CU (with 8 waves a CU holds one workgroup: 2 waves per SIMD)
@@ -2531,6 +2576,7 @@ static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* 
             hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, (hipStream_t)stream, a, loss_ws, freq);
         a.loss = loss_ws;
         kern = rt2d_gain_heatmap_kernel<true>;
+        if (!G && !G_end && !b.exact) kern = rt2d_gain_heatmap_kernel<true, true>;
     }
     ALLOW_LDS(kern, lds);
     if (n_launch > 0)
