@@ -571,6 +571,17 @@ def main():
                 'hbm_bytes_pmc': pb['hbm_bytes'], 'l2_atomics_pmc': pb['atomics'],
                 'atomics_per_s': None if pb['atomics'] is None else pb['atomics'] / t_bin,
                 'points_per_atomic': None if not pb['atomics'] else sl / pb['atomics'], 'pmc_source': pb['source']}
+        # the stored fan through the product API (its default for a fan this big: the one-pass map, queued without waiting)
+        product_step(rt, env, source, big_angles)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.large_steps):
+            fan_p2, hm_p2 = product_step(rt, env, source, big_angles)
+        torch.cuda.synchronize(); dtp = time.perf_counter() - t0
+        result['large_fan']['product_api'] = {
+            's_per_heatmap': dtp / args.large_steps, 'path': 'Simulation2D.cast + heatmap(): storing cast, one-pass gain + binning '
+            '(rt2d_gain_heatmap_rest), nothing read back before the end', 'passes': fan_p2.passes,
+            'max_abs_diff_vs_three_kernel_map': float((hm_p2 - hm_l).abs().max().item())}
+        del fan_p2, hm_p2
         # The same product WITHOUT keeping trajectories, through the product API: Simulation2D.cast(store=False) is lazy for a
         # fan this big, and heatmap() then casts it chunk by chunk WITH trajectories, bins each chunk through the stored
         # pipeline and drops it (RayFan.heatmap_accumulate_chunked): no counting pass, per-ray results as a by-product,

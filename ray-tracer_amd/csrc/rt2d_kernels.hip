@@ -2824,6 +2824,9 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
     RestSide* side = nullptr;
     int32_t rc = rest_side(&side);
     if (rc) return rc;
+    // (the side stream and its two events are shared by every caller on this device: one call queues at a time)
+    static std::mutex queue_mu;
+    std::lock_guard<std::mutex> queue_lock(queue_mu);
     hipStream_t main = (hipStream_t)stream;
     {   // rebound losses, once, on the caller's stream (the same launch gain_heatmap_impl would make)
         GainArgs a; memset(&a, 0, sizeof a);
