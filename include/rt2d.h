@@ -166,6 +166,14 @@ int32_t rt2d_traj_layout(const int32_t* n_pts, int64_t n, int64_t* tile_off, int
 int32_t rt2d_fan_summary(const int32_t* status, const double* range, const uint8_t* ray_mask, int64_t n,
                          const int64_t* tile_off, double* summary, void* stream);
 
+/* rt2d_traj_layout followed by rt2d_fan_summary of every ray, as one call -- and, for fans of at most 65 536 rays, as ONE
+ * launch that also writes ok_mask[r] = (status[r] == 0) when a mask is asked for (it must be NULL for bigger fans): a small
+ * fan's cast is followed by a dozen launches of a few microseconds each, and these four are one.  No zeroing of `summary`
+ * is needed: summary has n_summary >= 8 doubles, the 8 of rt2d_fan_summary and the caller's spare words behind them, which
+ * are set to zero.  Same outputs as the two calls (ray.py:466-472 for the range fold). */
+int32_t rt2d_layout_summary(const int32_t* n_pts, const int32_t* status, const double* range, int64_t n,
+                            int64_t* tile_off, double* summary, int32_t n_summary, uint8_t* ok_mask, void* stream);
+
 /* Same propagation, storing every point (reference: the np.insert at ray.py:192,216,236) in tile layout.
  * C (device, may be NULL) additionally receives the sound speed at every point (ray.py:273).
  * A tile never writes outside [tile_off[t], tile_off[t+1]): points beyond the tile's room are counted in n_pts but

@@ -1016,6 +1016,71 @@ __global__ void rt2d_tile_scan_kernel(int64_t n_tiles, int64_t* tile_off) {     
     }
 }
 
+// Everything that follows a small fan's cast in ONE launch (one block of 1024 threads, at most 1024 tiles): the exact
+// tile layout (rt2d_tile_len_kernel + rt2d_tile_scan_kernel), the fan's summary (rt2d_fan_summary_kernel, no zeroing
+// before it) and the mask of the error-free rays.  Four dependent launches of a few microseconds each otherwise, behind
+// a cast of 0.9 ms.
+__global__ void __launch_bounds__(1024) rt2d_small_summary_kernel(const int32_t* n_pts, const int32_t* status, const double* range,
+                                                                  int64_t n, int64_t n_tiles, int64_t* tile_off, double* summary,
+                                                                  int32_t n_summary, uint8_t* ok_mask) {
+    __shared__ int64_t s_len[1024];
+    __shared__ double s_part[16][7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t t = wave; t < 1024; t += 16) {
+        int v = 0;
+        if (t < n_tiles) {
+            const int64_t r = t * RT2D_WAVE + lane;
+            v = (r < n) ? n_pts[r] : 0;
+            for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+        }
+        if (lane == 0) s_len[t] = (int64_t)v * RT2D_WAVE;
+    }
+    __syncthreads();
+    double longest = (double)s_len[threadIdx.x];
+    for (int off = 1; off < n_tiles; off <<= 1) {              // inclusive scan (entries past the last tile are zero)
+        const int64_t add = (threadIdx.x >= off) ? s_len[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_len[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (threadIdx.x < n_tiles) tile_off[threadIdx.x + 1] = s_len[threadIdx.x];
+    if (threadIdx.x == 0) tile_off[0] = 0;
+    double ext[4] = {0.0, 0.0, 0.0, 0.0}, full = 0.0, n_ok = 0.0;
+    for (int64_t r = threadIdx.x; r < n; r += 1024) {
+        const int st = status[r];
+        if (ok_mask) ok_mask[r] = st == RT2D_RAY_OK ? 1 : 0;
+        if (st == RT2D_RAY_ERR_REBOUND_LOG) full = 1.0;
+        if (st != RT2D_RAY_OK) continue;
+        n_ok += 1.0;
+        const double lo_x = -range[r], lo_z = -range[n + r], hi_x = range[2 * n + r], hi_z = range[3 * n + r];
+        ext[0] = (lo_x > ext[0]) ? lo_x : ext[0];
+        ext[1] = (lo_z > ext[1]) ? lo_z : ext[1];
+        ext[2] = (hi_x > ext[2]) ? hi_x : ext[2];
+        ext[3] = (hi_z > ext[3]) ? hi_z : ext[3];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double o = __shfl_xor(ext[k], off); ext[k] = (o > ext[k]) ? o : ext[k]; }
+        const double ol = __shfl_xor(longest, off); longest = (ol > longest) ? ol : longest;
+        const double of = __shfl_xor(full, off); full = (of > full) ? of : full;
+        n_ok += __shfl_xor(n_ok, off);
+    }
+    if (lane == 0) {
+        s_part[wave][0] = longest; s_part[wave][1] = full; s_part[wave][2] = n_ok;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_part[wave][3 + k] = ext[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        double v = s_part[0][k];
+        for (int w = 1; w < 16; ++w) v = (k == 2) ? v + s_part[w][k] : ((s_part[w][k] > v) ? s_part[w][k] : v);
+        summary[1 + k] = v;                                  // longest -> [1], full -> [2], n_ok -> [3], ext -> [4..7]
+    }
+    if (threadIdx.x == 0) summary[0] = (double)s_len[n_tiles - 1];
+    if (threadIdx.x >= 8 && threadIdx.x < n_summary) summary[threadIdx.x] = 0.0;     // the caller's spare words start at zero
+}
+
 // copy every tile from a provisional (padded) layout into the exact one: within a tile both are [step][lane]
 // Everything the host needs to know about a finished cast in 8 doubles (RayPack2D.add's range fold ray.py:466-472 and
 // the checks behind the single-pass layouts): [0] points of the exact layout, [1] elements of its longest tile, [2] 1 if
@@ -2425,6 +2490,24 @@ int32_t rt2d_fan_summary(const int32_t* status, const double* range, const uint8
     const int64_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(rt2d_fan_summary_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream,
                        status, range, ray_mask, n, tile_off, n_tiles, summary);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_layout_summary(const int32_t* n_pts, const int32_t* status, const double* range, int64_t n,
+                            int64_t* tile_off, double* summary, int32_t n_summary, uint8_t* ok_mask, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!n_pts || !status || !range || !tile_off || !summary) return fail("rt2d_layout_summary: null argument");
+    if (n < 0) return fail("rt2d_layout_summary: negative ray count");
+    const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+    if (n_summary < 8 || n_summary > 1024) return fail("rt2d_layout_summary: the summary has 8 doubles (plus the caller's spare words)");
+    if (n_tiles == 0 || n_tiles > 1024) {
+        if (ok_mask) return fail("rt2d_layout_summary: the mask is only produced for fans of at most 65 536 rays");
+        if (n_summary > 8) HIP_OK(hipMemsetAsync(summary + 8, 0, (size_t)(n_summary - 8) * sizeof(double), stream));
+        int32_t rc = rt2d_traj_layout(n_pts, n, tile_off, nullptr, stream_);
+        return rc ? rc : rt2d_fan_summary(status, range, nullptr, n, tile_off, summary, stream_);
+    }
+    hipLaunchKernelGGL(rt2d_small_summary_kernel, dim3(1), dim3(1024), 0, stream, n_pts, status, range, n, n_tiles, tile_off, summary, n_summary, ok_mask);
     HIP_OK(hipGetLastError());
     return 0;
 }

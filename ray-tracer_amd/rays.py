@@ -135,6 +135,7 @@ class RayFan:
         self._summary = None
         self._init_host = init
         self._lazy_store = False
+        self._ok_mask = None       # (status == 0) as uint8, when the cast's summary launch produced it
         # lazy (store=False only): nothing is cast until something asks for a per-ray result -- a heat map asked for first
         # (heatmap_accumulate_chunked) then produces them on its way, and no counting pass ever runs
         self._uncast = bool(lazy) and not self.store and self.n > 0
@@ -288,8 +289,16 @@ class RayFan:
                 C0 = torch.empty(n_tiles * room * TILE, **f64) if store_c else None
                 cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
                 exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
-                _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
-                self._queue_summary(exact, stream)
+                if n_tiles <= 1024:
+                    # small fan: exact layout, summary and the mask of the error-free rays in ONE launch
+                    self._summary_dev = torch.empty(SUMMARY_LEN, dtype=torch.float64, device=dev)
+                    self._ok_mask = torch.empty(n, dtype=torch.uint8, device=dev)
+                    _lib.check(L.rt2d_layout_summary(self.n_pts.data_ptr(), self.status.data_ptr(), self.range.data_ptr(), n,
+                                                     exact.data_ptr(), self._summary_dev.data_ptr(), SUMMARY_LEN,
+                                                     self._ok_mask.data_ptr(), stream))
+                else:
+                    _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
+                    self._queue_summary(exact, stream)
                 self.tile_off, self._tile_off_exact = off0, exact
                 self.X, self.Z, self.Cpt = X0, Z0, C0
                 self.total = n_tiles * room * TILE
@@ -895,8 +904,9 @@ class RayFan:
         with torch.cuda.device(self.device):
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
-            work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device) if fast else None
-            if fast and hint and self.n > HEATMAP_FAST_MIN_RAYS:       # smaller fans go through the general kernel anyway
+            fast = fast and self.n > HEATMAP_FAST_MIN_RAYS               # smaller fans go through the general kernel anyway (no
+            work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device) if fast else None     # work list, no launch to mark it)
+            if fast and hint:
                 ray_mask = self.heatmap_mask(res, shape, ray_mask)
             _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
                                                  self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,

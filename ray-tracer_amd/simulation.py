@@ -145,14 +145,15 @@ class Simulation2D:
                 else:
                     a = fan.angles_dev
                     distinct = (a[1:] > a[:-1]).all() | (a[1:] < a[:-1]).all()
-            H = torch.zeros(int(shape_b[0]) * int(shape_b[1]), dtype=torch.float64, device=device)
-            dropped = torch.zeros(1, dtype=torch.int64, device=device)
+            cells = int(shape_b[0]) * int(shape_b[1])
+            zeroed = torch.zeros(cells + 1, dtype=torch.float64, device=device)      # the map and the dropped-points counter: one fill
+            H, dropped = zeroed[:cells], zeroed[cells:].view(torch.int64)
             if lazy:
                 # no trajectories kept and nothing cast yet: chunk by chunk (cast with trajectories -> bin -> drop)
                 if not fan.heatmap_accumulate_chunked(H, res, shape_b, freq=kwargs.get('freq', 1), dropped=dropped):
                     return None
             else:
-                mask = (fan.status == 0).to(torch.uint8)
+                mask = fan._ok_mask if getattr(fan, '_ok_mask', None) is not None else (fan.status == 0).to(torch.uint8)
                 fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
                                        fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None),
                                        defer=True)
