@@ -357,7 +357,7 @@ class RayFan:
         if longest <= self._room * TILE and not log_full:
             return False
         self._force_exact = True
-        self.G, self.G_end, self._post, self._host, self._scalars = {}, {}, None, {}, None
+        self.G, self.G_end, self._post, self._host, self._scalars, self._ok_mask = {}, {}, None, {}, None, None
         self._cast(self._init_host, self.Cpt is not None)
         return True
 
