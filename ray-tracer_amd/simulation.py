@@ -8,6 +8,7 @@ cast instead of looping ``for angle in angles`` (simulation.py:89-94).
 """
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -115,19 +116,29 @@ class Simulation2D:
             res = res.astype(np.int64)
         return res
 
-    def _heatmap_one_fan(self, fan, res, kwargs, finalize):
+    def _heatmap_one_fan(self, fan, res, kwargs, finalize, dist_on=False):
         """Heat map of a pack that is ONE whole fan, without waiting for the device before the end: the map is binned
         into the shape of the environment's rectangle (an upper bound of the plot range, known on the host), normalised
         there, and cropped to ceil(size_plot / res) + 1 (simulation.py:117) once the fan's summary -- plot range, "every
         ray fitted its room" -- has been read, in the one device -> host read of the whole cast + heat map.  Valid when
         no ray starts left of x = 0 or rises above z = 1 (then every point falls inside both maps, at the same cell);
-        returns None otherwise, or when the fan had to be cast again, and the caller takes the general path."""
+        returns None otherwise, or when the fan had to be cast again, and the caller takes the general path.
+
+        dist_on (the fan is this rank's share of a sharded cast): the same with the two collectives queued on the stream --
+        the ranks' maps are summed in the rectangle's shape (C2) and the plot range is combined (C1) AFTER the binning, which
+        does not need it here -- so that a rank still reads the device once per heat map.  Every rank must take the same
+        decisions: whatever would make one rank leave this path (a fan cast again, repeated angles, an empty share) travels
+        as a flag in C1's max, and then all ranks leave it together.  Only what is the same on all ranks (environment,
+        resolution) may return before the collectives."""
         torch = _torch()
         env = self.env
         lo = np.minimum(0., np.asarray(env.range_min, dtype=np.float64))
         hi = np.maximum(0., np.asarray(env.range_max, dtype=np.float64))
         lazy = bool(fan.__dict__.get('_uncast'))
-        if lo[0] <= -1 or hi[1] >= 1 + 1e-9 or fan.n == 0 or not (fan._pending or lazy):
+        if lo[0] <= -1 or hi[1] >= 1 + 1e-9:
+            return None
+        bad = fan.n == 0                                   # (local reasons to leave: returned at once alone, flagged among ranks)
+        if not dist_on and (bad or not (fan._pending or lazy)):
             return None
         shape_b = parallel.heatmap_shape(lo, hi, res)
         if int(shape_b[0]) * int(shape_b[1]) >= (1 << 28):
@@ -141,22 +152,47 @@ class Simulation2D:
                 if fan._angles_host is not None:
                     step = np.diff(fan._angles_host)
                     if not (bool((step > 0).all()) or bool((step < 0).all())):
-                        return None
+                        if not dist_on:
+                            return None
+                        bad = True
                 else:
                     a = fan.angles_dev
                     distinct = (a[1:] > a[:-1]).all() | (a[1:] < a[:-1]).all()
             cells = int(shape_b[0]) * int(shape_b[1])
             zeroed = torch.zeros(cells + 1, dtype=torch.float64, device=device)      # the map and the dropped-points counter: one fill
             H, dropped = zeroed[:cells], zeroed[cells:].view(torch.int64)
-            if lazy:
+            if bad:
+                pass
+            elif lazy:
                 # no trajectories kept and nothing cast yet: chunk by chunk (cast with trajectories -> bin -> drop)
                 if not fan.heatmap_accumulate_chunked(H, res, shape_b, freq=kwargs.get('freq', 1), dropped=dropped):
-                    return None
+                    if not dist_on:
+                        return None
+                    bad = True
             else:
                 mask = fan._ok_mask if getattr(fan, '_ok_mask', None) is not None else (fan.status == 0).to(torch.uint8)
                 fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
                                        fast=kwargs.get('fast', True), hint=kwargs.get('hint', True), stream=kwargs.get('stream', None),
                                        defer=True)
+            ext = None
+            if dist_on:
+                # C1 and the flag in one max-all-reduce of five numbers, C2 (with the dropped-point count as a sixth map cell):
+                # both on the stream, nothing read yet
+                f64 = dict(dtype=torch.float64, device=device)
+                ext = torch.zeros(5, **f64)
+                sd = getattr(fan, '_summary_dev', None)
+                if sd is not None and not bad:
+                    ext[:4] = sd[4:8]
+                    if fan._pending:
+                        ext[4] = ((sd[1] > float(fan._room * 64)) | (sd[2] != 0) | (sd[8] != 0)).to(torch.float64)
+                    if distinct is not None:
+                        ext[4] = torch.maximum(ext[4], (~distinct).to(torch.float64))
+                else:
+                    ext[4] = 1.0
+                parallel._all_reduce(ext, parallel._dist().ReduceOp.MAX)
+                zeroed[cells] = dropped[0].to(torch.float64)                      # (the counter travels as a double in the same sum)
+                parallel.allreduce_heatmap(zeroed)
+                dropped = zeroed[cells:].round().to(torch.int64)
             out_b = None
             if finalize:
                 out_b = torch.empty((int(shape_b[1]), int(shape_b[0])), dtype=torch.float64, device=device)
@@ -166,6 +202,16 @@ class Simulation2D:
                                                             float(kwargs.get('reduction_power', .5)), out_b.data_ptr(),
                                                             scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
             # -- the one read --
+            if dist_on:
+                got = ext.tolist()
+                fan.validate()                                # (a fan that must be cast again is, before every rank starts over)
+                if got[4] != 0:
+                    return None
+                rmin, rmax = -np.array(got[0:2]), np.array(got[2:4])
+                if rmin[0] <= -1 or rmax[1] >= 1:
+                    return None                               # (the combined range: the same verdict on every rank)
+                shape = parallel.heatmap_shape(rmin, rmax, res)
+                return H.view(int(shape_b[0]), int(shape_b[1])), out_b, shape, dropped
             if fan.validate() or getattr(fan, '_onepass_overflow', False):
                 return None                                   # cast again with counted sizes, or a one-pass map without rows
                                                               # enough for its side rays: start over
@@ -189,8 +235,9 @@ class Simulation2D:
         raypack = self.raypacks[kwargs.get('pack', self.pack_default)]
         dist_on = getattr(raypack, 'sharded', False) and parallel.active()
         fan = raypack._sole_pending_fan()
-        if fan is not None and (fan.store or fan.__dict__.get('_uncast')) and not dist_on and not kwargs.get('stream', None):
-            got = self._heatmap_one_fan(fan, res, kwargs, finalize)
+        one_fan_dist = os.environ.get('RT2D_DIST_ONE_FAN', '1') != '0'            # (0: the general path for sharded packs, as before round 2)
+        if fan is not None and (fan.store or fan.__dict__.get('_uncast')) and not kwargs.get('stream', None) and (one_fan_dist or not dist_on):
+            got = self._heatmap_one_fan(fan, res, kwargs, finalize, dist_on=dist_on)
             if got is not None:
                 Hb, out_b, shape, dropped = got
                 nx, nz = int(shape[0]), int(shape[1])

@@ -33,6 +33,15 @@ def main():
         out[f'{mode}_H'] = H.cpu().numpy()
         out[f'{mode}_n_local'] = np.int64(fan.n)
         out[f'{mode}_plot'] = sim.heatmap(resolution=[50, 25], cutoff=.1)
+    # one rank's share holds an angle twice (positions 3 and 5 of the interleaved deal are both rank 1's): that rank cannot
+    # take the one-read path (the pack keeps the first ray of an angle only) and says so in C1's max; BOTH ranks then take
+    # the general path, with its collectives in its order
+    g = common.load('c2_fan999')
+    dup = np.array(g['fan_angles'][:200], dtype=np.float64)
+    dup[5] = dup[3]
+    sim = rt.Simulation2D(common.product_env(rt, g), g['fan_source'], distributed=True, shard='interleave')
+    sim.cast(dup, sort=False, **common.prop_kwargs(g))
+    out['dup_H'] = sim.heatmap_full(resolution=[50, 25])[0].cpu().numpy()
     g = common.load('c5_eigen')
     sim = rt.EigenraySim2D(common.product_env(rt, g), g['source'], g['target'], int(g['n_rays']), int(g['n_rebounds_max']),
                            n_rays_scan=int(g['n_rays_scan']), scan_angle_min=float(g['scan_angle_min']),

@@ -39,6 +39,14 @@ def test_two_ranks_equal_one_process(rt, tmp_path):
             assert np.abs(got[r][f'{mode}_plot'] - plot).max() < 1e-12
         assert np.array_equal(got[0][f'{mode}_H'], got[1][f'{mode}_H'])       # every rank holds the same map
 
+    dup = np.array(g['fan_angles'][:200], dtype=np.float64)
+    dup[5] = dup[3]
+    sim = rt.Simulation2D(common.product_env(rt, g), g['fan_source'])
+    sim.cast(dup, sort=False, **common.prop_kwargs(g))
+    Hd = sim.heatmap_full(resolution=[50, 25])[0].cpu().numpy()
+    for r in range(2):
+        assert got[r]['dup_H'].shape == Hd.shape and np.abs(got[r]['dup_H'] - Hd).max() <= 1e-12 * Hd.max()
+
     g = common.load('c5_eigen')
     assert int(got[0]['scan_n_local']) + int(got[1]['scan_n_local']) == int(g['n_rays_scan'])
     for r in range(2):
