@@ -73,6 +73,26 @@ def _side_stream(device, which=0):
 
 
 _FREQ_TENSORS = {}
+_ANGLE_TENSORS = {}
+
+
+def _angles_on_device(host, device):
+    """Device copy of a host angle array.  A copy from pageable memory waits for the transfer (~15 us even for 8 KB, on
+    the critical path in front of every cast): the copies of the last few small arrays are kept and found again by
+    content (hash of the bytes, then an equality check), e.g. the same sweep cast again and again.  Nothing ever writes
+    to a fan's angles."""
+    import torch
+    if host.size > (1 << 16):
+        return torch.from_numpy(host).to(device)
+    key = (str(device), host.size, hash(host.tobytes()))
+    hit = _ANGLE_TENSORS.get(key)
+    if hit is not None and np.array_equal(hit[0], host):
+        return hit[1]
+    t = torch.from_numpy(host).to(device)
+    if len(_ANGLE_TENSORS) >= 16:
+        _ANGLE_TENSORS.pop(next(iter(_ANGLE_TENSORS)))
+    _ANGLE_TENSORS[key] = (host.copy(), t)
+    return t
 
 
 def _freq_tensor(freqs, device):
@@ -124,7 +144,7 @@ class RayFan:
             self._angles_host = None
         else:
             self._angles_host = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
-            self.angles_dev = torch.from_numpy(self._angles_host).to(self.device)
+            self.angles_dev = _angles_on_device(self._angles_host, self.device)
         self.n = int(self.angles_dev.shape[0])
         self._host = {}
         self.G = {}            # freq -> device tensor (total,) in tile layout
@@ -169,17 +189,29 @@ class RayFan:
             n8 = (n + 7) // 8 * 8
             buf = torch.empty(8 * n8 * 8, dtype=torch.uint8, device=dev)          # 5 doubles + 4 ints + 1 byte per ray, rounded up
 
-            def carve(first_double, count, dtype):
-                nbytes = count * {torch.float64: 8, torch.int32: 4, torch.uint8: 1}[dtype]
-                return buf[first_double * 8:first_double * 8 + nbytes].view(dtype)
+            # The tensors are views into it; making a view costs the host ~2 us and there are two dozen of them (with the
+            # rebound log): the kernel only needs ADDRESSES, so the single-pass cast is launched from the addresses and the
+            # views are made while it runs (make_views; every other path makes them first).
+            nbytes_of = {torch.float64: 8, torch.int32: 4, torch.uint8: 1}
+            addr, todo = {}, []
 
-            self.range = carve(0, 4 * n, torch.float64).view(4, n)
-            self.slope_max = carve(4 * n8, n, torch.float64)
-            self.n_pts = carve(5 * n8, n, torch.int32)
-            self.stop_code = carve(5 * n8 + n8 // 2, n, torch.int32)
-            self.n_rebounds = carve(6 * n8, n, torch.int32)
-            self.status = carve(6 * n8 + n8 // 2, n, torch.int32)
-            self.monotone = carve(7 * n8, n, torch.uint8)
+            def carve(name, first_double, count, dtype, shape=None, src=None, src_ptr=None):
+                addr[name] = (buf.data_ptr() if src is None else src_ptr) + first_double * 8
+                todo.append((name, first_double, count, dtype, shape, buf if src is None else src))
+
+            def make_views():
+                while todo:
+                    name, first_double, count, dtype, shape, src_t = todo.pop(0)
+                    v = src_t[first_double * 8:first_double * 8 + count * nbytes_of[dtype]].view(dtype)
+                    setattr(self, name, v if shape is None else v.view(*shape))
+
+            carve('range', 0, 4 * n, torch.float64, (4, n))
+            carve('slope_max', 4 * n8, n, torch.float64)
+            carve('n_pts', 5 * n8, n, torch.int32)
+            carve('stop_code', 5 * n8 + n8 // 2, n, torch.int32)
+            carve('n_rebounds', 6 * n8, n, torch.int32)
+            carve('status', 6 * n8 + n8 // 2, n, torch.int32)
+            carve('monotone', 7 * n8, n, torch.uint8)
             self._scalars = None
             if self.target is not None:
                 self.dist = torch.full((n,), float('nan'), **f64)
@@ -196,13 +228,13 @@ class RayFan:
 
             def full_out():
                 out = _lib.Rt2dRayOut()
-                out.n_pts, out.stop_code = self.n_pts.data_ptr(), self.stop_code.data_ptr()
-                out.n_rebounds, out.status = self.n_rebounds.data_ptr(), self.status.data_ptr()
+                out.n_pts, out.stop_code = addr['n_pts'], addr['stop_code']
+                out.n_rebounds, out.status = addr['n_rebounds'], addr['status']
                 # the bounding box is all the heat-map pipeline needs of the post-pass; L_end / T_end / margin are
                 # produced on demand (_lazy_scalars) so that the main cast does not carry them through every step
-                out.range = self.range.data_ptr()
-                out.monotone = self.monotone.data_ptr()
-                out.slope_max = self.slope_max.data_ptr()
+                out.range = addr['range']
+                out.monotone = addr['monotone']
+                out.slope_max = addr['slope_max']
                 if self.target is not None:
                     out.dist_to_target, out.step_target = self.dist.data_ptr(), self.step_target.data_ptr()
                     out.T_target = self.T_target.data_ptr()
@@ -216,17 +248,14 @@ class RayFan:
                 m8 = (m + 7) // 8 * 8
                 lb = torch.empty((4 * m8 + m8 // 2 + m8 // 8) * 8, dtype=torch.uint8, device=dev)
 
-                def part(first_double, dtype):
-                    nbytes = m * {torch.float64: 8, torch.int32: 4, torch.uint8: 1}[dtype]
-                    return lb[first_double * 8:first_double * 8 + nbytes].view(dtype).view(cap, n)
-
-                self.reb_velocity, self.reb_angle = part(0, torch.float64), part(m8, torch.float64)
-                self.reb_pos_x, self.reb_pos_z = part(2 * m8, torch.float64), part(3 * m8, torch.float64)
-                self.reb_step = part(4 * m8, torch.int32)
-                self.reb_surface = part(4 * m8 + m8 // 2, torch.uint8)
-                out.reb_step, out.reb_surface = self.reb_step.data_ptr(), self.reb_surface.data_ptr()
-                out.reb_velocity, out.reb_angle = self.reb_velocity.data_ptr(), self.reb_angle.data_ptr()
-                out.reb_pos_x, out.reb_pos_z = self.reb_pos_x.data_ptr(), self.reb_pos_z.data_ptr()
+                lp = lb.data_ptr()
+                for name, first, dtype in (('reb_velocity', 0, torch.float64), ('reb_angle', m8, torch.float64),
+                                           ('reb_pos_x', 2 * m8, torch.float64), ('reb_pos_z', 3 * m8, torch.float64),
+                                           ('reb_step', 4 * m8, torch.int32), ('reb_surface', 4 * m8 + m8 // 2, torch.uint8)):
+                    carve(name, first, m, dtype, (cap, n), lb, lp)
+                out.reb_step, out.reb_surface = addr['reb_step'], addr['reb_surface']
+                out.reb_velocity, out.reb_angle = addr['reb_velocity'], addr['reb_angle']
+                out.reb_pos_x, out.reb_pos_z = addr['reb_pos_x'], addr['reb_pos_z']
 
             def cast_write(out, cap, tile_off, X, Z, Cpt):
                 p = self._params(cap)
@@ -240,8 +269,10 @@ class RayFan:
             self.padded = False
             self.passes = 'count'
             if n == 0 or alloc_only:
+                make_views()
                 return
             if not self.store:
+                make_views()
                 # scalars only: one pass with the post-pass folded in.  With a bounded rebound count the rebound log is kept
                 # too (37 B per rebound): the fused heat-map kernel reads its rebound losses from it (heatmap_accumulate_fused)
                 out = full_out()
@@ -251,6 +282,7 @@ class RayFan:
                 p = self._params(self.rebound_cap)
                 _lib.check(L.rt2d_cast_count(handle, self.angles_dev.data_ptr(), n, src, C.byref(p), _ptr(init_slope),
                                              _ptr(init_mult), C.byref(out), stream))
+                make_views()
                 self._out = out
                 return
             n_tiles = (n + TILE - 1) // TILE
@@ -273,6 +305,7 @@ class RayFan:
             fits = layout_bytes <= SPECULATIVE_BYTES or (layout_bytes <= PADDED_BYTES and
                                                          layout_bytes * 1.6 <= _free_bytes(dev))
             if known_n_pts is not None:
+                make_views()
                 self.n_pts.copy_(known_n_pts)        # point counts from an earlier cast of these rays: no counting pass
                 counted = True
             elif fits and not self._force_exact:
@@ -288,6 +321,7 @@ class RayFan:
                 Z0 = torch.empty(n_tiles * room * TILE, **f64)
                 C0 = torch.empty(n_tiles * room * TILE, **f64) if store_c else None
                 cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
+                make_views()                           # (the cast is running)
                 exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
                 if n_tiles <= 1024:
                     # small fan: exact layout, summary and the mask of the error-free rays in ONE launch
@@ -311,6 +345,7 @@ class RayFan:
 
             # pass 1: count points and rebounds only (no post-pass, no stores) -- unless a single-pass attempt above
             # already did: it stops storing at its room but steps and counts to the end
+            make_views()
             if not counted:
                 cnt = _lib.Rt2dRayOut()
                 cnt.n_pts, cnt.n_rebounds = self.n_pts.data_ptr(), self.n_rebounds.data_ptr()
@@ -330,6 +365,7 @@ class RayFan:
             self.Z = torch.empty(self.total, **f64)
             self.Cpt = torch.empty(self.total, **f64) if store_c else None
             cast_write(out, self.rebound_cap, self.tile_off, self.X, self.Z, self.Cpt)
+            make_views()
             self._out = out
             self.passes = 'count+store'
             self._queue_summary(self.tile_off, stream)
