@@ -76,6 +76,16 @@ _FREQ_TENSORS = {}
 _ANGLE_TENSORS = {}
 
 
+def _raw_stream():
+    """hipStream_t of torch's current stream on the current device, as an integer.  torch.cuda.current_stream() costs the
+    host ~10 us (a Python object per call); the raw query behind it a fraction of one."""
+    import torch
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:                      # (a torch without the private query)
+        return torch.cuda.current_stream().cuda_stream
+
+
 def _angles_on_device(host, device):
     """Device copy of a host angle array.  A copy from pageable memory waits for the transfer (~15 us even for 8 KB, on
     the critical path in front of every cast): the copies of the last few small arrays are kept and found again by
@@ -182,7 +192,7 @@ class RayFan:
         n, dev = self.n, self.device
         with torch.cuda.device(dev):
             handle = self.env.device_handle(dev.index)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream()
             f64 = dict(dtype=torch.float64, device=dev)
             i32 = dict(dtype=torch.int32, device=dev)
             # every per-ray result out of ONE allocation (a dozen small ones cost the host more than the cast's launch)
@@ -413,7 +423,7 @@ class RayFan:
                     p = self._params(0)
                     _lib.check(_lib.lib().rt2d_cast_count(self.env.device_handle(self.device.index), self.angles_dev.data_ptr(),
                                                          self.n, src, C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]),
-                                                         C.byref(out), torch.cuda.current_stream().cuda_stream))
+                                                         C.byref(out), _raw_stream()))
             self._scalars = d
         return self._scalars
 
@@ -498,7 +508,7 @@ class RayFan:
         torch = _torch()
         L = _lib.lib()
         with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream()
             f64 = dict(dtype=torch.float64, device=self.device)
             exact = self._tile_off_exact
             total = int(self._summary[0]) if self._summary is not None else int(exact[-1].item())
@@ -568,7 +578,7 @@ class RayFan:
                 _lib.check(L.rt2d_post(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
                                        self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, d['dL'].data_ptr(),
                                        d['L'].data_ptr(), d['C'].data_ptr(), d['dT'].data_ptr(), d['T'].data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream))
+                                       _raw_stream()))
             self._post = d
         return self._post
 
@@ -596,7 +606,7 @@ class RayFan:
             _lib.check(L.rt2d_gain(self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(),
                                    self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out),
                                    self.rebound_cap, self.n, fr.data_ptr(), len(new), self.total, _ptr(G),
-                                   G_end.data_ptr(), _ptr(loss_ws), torch.cuda.current_stream().cuda_stream))
+                                   G_end.data_ptr(), _ptr(loss_ws), _raw_stream()))
         for k, f in enumerate(new):
             if G is not None:
                 self.G[f] = G[k]
@@ -611,7 +621,7 @@ class RayFan:
             out = torch.empty(self.n, dtype=torch.float64, device=self.device)
             tgt = (C.c_double * 2)(float(target[0]), float(target[1]))
             _lib.check(L.rt2d_dist(self.X.data_ptr(), self.Z.data_ptr(), self.tile_off.data_ptr(), self.n_pts.data_ptr(),
-                                   self.n, tgt, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                   self.n, tgt, out.data_ptr(), _raw_stream()))
         return out
 
     # -- heat map (simulation.py:120-131) ---------------------------------------------------------
@@ -655,7 +665,7 @@ class RayFan:
             p = self._params(0)
             viol = torch.zeros(1, dtype=torch.int64, device=self.device)
             handle = self.env.device_handle(self.device.index)
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream()
             loss, cap = None, 0
             if self.rebound_cap > 0 and self.rebound_cap * self.n * 8 <= LOSS_WS_BYTES:
                 # the rebound losses at this frequency from the count pass's log, by their own kernel (rt2d_rebound_loss)
@@ -794,7 +804,7 @@ class RayFan:
             self._last_slow = slow if isinstance(slow, int) else slow.reshape(1)
             if first:
                 if not adopt:
-                    stream = torch.cuda.current_stream().cuda_stream
+                    stream = _raw_stream()
                     n_tiles = (n + TILE - 1) // TILE
                     exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=self.device)
                     _lib.check(L.rt2d_traj_layout(self.n_pts.data_ptr(), n, exact.data_ptr(), None, stream))
@@ -824,7 +834,7 @@ class RayFan:
                 # deals the side rays rows of a compact gain array sized by bounds (a row = the room of the provisional
                 # layout, n / 8 rows); "ran out of rows" lands in the word behind the fan's summary, and the caller --
                 # who reads the summary anyway (validate) -- then bins the fan again with known sizes (defer=False).
-                stream = torch.cuda.current_stream().cuda_stream
+                stream = _raw_stream()
                 rows, g_room = max(ONEPASS_MIN_ROWS, self.n // ONEPASS_ROWS_DIV), int(self._room)
                 m = torch.empty(self.n, dtype=torch.uint8, device=self.device)
                 slot = torch.empty(self.n, dtype=torch.int32, device=self.device)
@@ -849,7 +859,7 @@ class RayFan:
                 return
             self.validate()                              # the masks below need the final cast
             self._onepass_overflow = False
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _raw_stream()
             sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
             m = self.fused_mask(res, shape, ray_mask)
             rest = sel & (m == 0)
@@ -893,7 +903,7 @@ class RayFan:
             _lib.check(L.rt2d_heatmap_accumulate_multi(self.X.data_ptr(), self.Z.data_ptr(), ptrs.data_ptr(), len(freqs),
                                                        self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, _ptr(ray_mask),
                                                        res_c, shape_c, H.data_ptr(), _ptr(dropped), work.data_ptr(),
-                                                       torch.cuda.current_stream().cuda_stream))
+                                                       _raw_stream()))
             self._last_slow = work
 
     @property
@@ -947,7 +957,7 @@ class RayFan:
             _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
                                                  self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
                                                  _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),
-                                                 torch.cuda.current_stream().cuda_stream))
+                                                 _raw_stream()))
             self._last_slow = work if fast else self.n                   # rays binned by the general kernel: read on demand
 
 

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-from .rays import RayFan, RayPack2D, _torch
+from .rays import RayFan, RayPack2D, _torch, _raw_stream
 from . import _lib
 from . import rays as rays_mod
 from . import parallel
@@ -200,7 +200,7 @@ class Simulation2D:
                 shape_c = (C.c_int32 * 2)(int(shape_b[0]), int(shape_b[1]))
                 _lib.check(_lib.lib().rt2d_heatmap_finalize(H.data_ptr(), shape_c, float(kwargs.get('cutoff', .02)),
                                                             float(kwargs.get('reduction_power', .5)), out_b.data_ptr(),
-                                                            scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                            scratch.data_ptr(), _raw_stream()))
             # -- the one read --
             if dist_on:
                 got = ext.tolist()
@@ -271,7 +271,7 @@ class Simulation2D:
         with torch.cuda.device(H.device):
             _lib.check(_lib.lib().rt2d_heatmap_finalize(H.data_ptr(), shape_c, float(kwargs.get('cutoff', .02)),
                                                         float(kwargs.get('reduction_power', .5)), out.data_ptr(),
-                                                        scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                        scratch.data_ptr(), _raw_stream()))
         return out, dropped
 
     def heatmap(self, **kwargs):
@@ -325,7 +325,7 @@ class Simulation2D:
             scratch = torch.empty(2 * F, dtype=torch.float64, device=device)
             _lib.check(_lib.lib().rt2d_heatmap_finalize_multi(H.data_ptr(), (C.c_int32 * 2)(nx, nz), F, float(kwargs.get('cutoff', .02)),
                                                               float(kwargs.get('reduction_power', .5)), out.data_ptr(),
-                                                              scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                                                              scratch.data_ptr(), _raw_stream()))
         if kwargs.get('as_tensor', False):
             return {f: out[k] for k, f in enumerate(freqs)}
         # one copy of all maps through page-locked memory (38 MB for 64 maps of 1500 x 51: 10 ms pageable, 2 ms pinned)
@@ -551,7 +551,7 @@ class EigenraySim2D(Simulation2D):
                 _lib.check(_lib.lib().rt2d_target_products(
                     self.env.device_handle(fan.device.index), fan.X.data_ptr(), fan.Z.data_ptr(), T.data_ptr(), ptrs.data_ptr(),
                     fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), ids.data_ptr(), k, tgt, fr.data_ptr(), len(fl),
-                    step.data_ptr(), T_t.data_ptr(), Tm.data_ptr(), torch.cuda.current_stream().cuda_stream))
+                    step.data_ptr(), T_t.data_ptr(), Tm.data_ptr(), _raw_stream()))
             ang.append(np.asarray(fan.angles, dtype=np.float64)[np.asarray(idx, dtype=np.int64)])
             T_all.append(T_t.cpu().numpy())
             Tm_all.append(Tm.cpu().numpy().T)
