@@ -1395,7 +1395,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_dg_kernel(const GainArgs a) {
 #define GAIN_SCAN_PER_THREAD (GAIN_SCAN_ROWS * RT2D_WAVE / GAIN_SCAN_THREADS)
 __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const GainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_buf[];          // [ROWS][64] chunk, then the loss table
-    double* s_loss = s_buf + GAIN_SCAN_ROWS * RT2D_WAVE;                   // [cap][64] cumulative rebound loss
+    double* s_loss = s_buf + 3 * GAIN_SCAN_ROWS * RT2D_WAVE;               // [cap][64] cumulative rebound loss (behind the three chunk buffers)
     int* s_at = reinterpret_cast<int*>(s_loss + (size_t)a.rebound_cap * RT2D_WAVE);   // [cap][64] first point carrying it
     const int lane = threadIdx.x & 63;
     const bool scanner = threadIdx.x < RT2D_WAVE;
@@ -1435,53 +1435,68 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
         for (int k = 0; k < nreb; ++k) { A += s_loss[k * RT2D_WAVE + lane]; s_loss[k * RT2D_WAVE + lane] = A; }
     }
     __syncthreads();
-    // Division of labour per chunk: every thread zeroes the entries past its ray's end while filling LDS, wave 0 runs
-    // the bare running sums S (one dependent add per point), and every thread adds the rebound loss A of its point on
-    // the way out: G = S + A as in the one-pass kernel.  A thread meets its column's points in increasing order, so the
-    // loss in force is a cursor into the column's table.
+    // Division of labour, pipelined over three LDS buffers: the fifteen loader waves fill chunk k (zeroing the entries past
+    // a ray's end) and write chunk k - 2 out with the rebound loss A of each point added (G = S + A as in the one-pass
+    // kernel), while wave 0 runs the bare running sums S of chunk k - 1 (one dependent add per point: the reference's
+    // cumsum, in its order) -- one barrier per chunk, and the sums never wait for memory.  A loader thread meets its
+    // column's points in increasing order, so the loss in force is a cursor into the column's table.
     int next_reb = 0;
     int next_reb_at = (nreb > 0) ? s_at[lane] : 0x7fffffff;
     double A = 0.0, S = 0.0;
-    const int row0 = threadIdx.x >> 6;                  // row of this thread's first element inside a chunk
-    constexpr int ROW_STEP = GAIN_SCAN_THREADS / RT2D_WAVE;
+    constexpr int LOADERS = GAIN_SCAN_THREADS / RT2D_WAVE - 1;              // waves 1 .. 15
+    constexpr int ROWS_PER_LOADER = (GAIN_SCAN_ROWS + LOADERS - 1) / LOADERS;
+    const int lw = (threadIdx.x >> 6) - 1;                                  // loader index, -1 for the scanner wave
     const int64_t chunk = (int64_t)GAIN_SCAN_ROWS * RT2D_WAVE;
     const int64_t last = len - 1;
-    double regs[GAIN_SCAN_PER_THREAD];
+    const int n_chunks = (int)((len + chunk - 1) / chunk);
+    double regs[ROWS_PER_LOADER];
+    if (!scanner) {
 #pragma unroll
-    for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k) regs[k] = G[min((int64_t)(threadIdx.x + GAIN_SCAN_THREADS * k), last)];
-    for (int64_t c0 = 0; c0 < len; c0 += chunk) {
-        const int s_first = (int)(c0 >> 6);
+        for (int k = 0; k < ROWS_PER_LOADER; ++k)
+            regs[k] = G[min((int64_t)(lw + LOADERS * k) * RT2D_WAVE + lane, last)];
+    }
+    for (int it = 0; it < n_chunks + 2; ++it) {
+        if (!scanner) {
+            if (it < n_chunks) {
+                double* buf = s_buf + (it % 3) * chunk;
+                const int s_first = it * GAIN_SCAN_ROWS;
 #pragma unroll
-        for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k) {
-            const int sx = s_first + row0 + ROW_STEP * k;
-            s_buf[threadIdx.x + GAIN_SCAN_THREADS * k] = (sx >= 1 && sx < np) ? regs[k] : 0.0;
-        }
+                for (int k = 0; k < ROWS_PER_LOADER; ++k) {
+                    const int row = lw + LOADERS * k;
+                    const int sx = s_first + row;
+                    if (row < GAIN_SCAN_ROWS) buf[row * RT2D_WAVE + lane] = (sx >= 1 && sx < np) ? regs[k] : 0.0;
+                }
 #pragma unroll
-        for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k)                      // next chunk on its way during the sums
-            regs[k] = G[min(c0 + chunk + threadIdx.x + GAIN_SCAN_THREADS * k, last)];
-        __syncthreads();
-        if (scanner) {
+                for (int k = 0; k < ROWS_PER_LOADER; ++k)                  // the next chunk on its way during the sums
+                    regs[k] = G[min((int64_t)(it + 1) * chunk + (int64_t)(lw + LOADERS * k) * RT2D_WAVE + lane, last)];
+            }
+            if (it >= 2) {
+                const double* buf = s_buf + ((it - 2) % 3) * chunk;
+                const int s_first = (it - 2) * GAIN_SCAN_ROWS;
+#pragma unroll
+                for (int k = 0; k < ROWS_PER_LOADER; ++k) {
+                    const int row = lw + LOADERS * k;
+                    const int sx = s_first + row;
+                    if (row < GAIN_SCAN_ROWS && sx < np) {
+                        while (sx >= next_reb_at) {
+                            A = s_loss[next_reb * RT2D_WAVE + lane];
+                            ++next_reb;
+                            next_reb_at = (next_reb < nreb) ? s_at[next_reb * RT2D_WAVE + lane] : 0x7fffffff;
+                        }
+                        G[(int64_t)sx * RT2D_WAVE + lane] = buf[row * RT2D_WAVE + lane] + A;
+                    }
+                }
+            }
+        } else if (it >= 1 && it <= n_chunks) {
+            double* buf = s_buf + ((it - 1) % 3) * chunk;
             for (int rb = 0; rb < GAIN_SCAN_ROWS; rb += 16) {
                 double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = s_buf[(rb + u) * RT2D_WAVE + lane];
+                for (int u = 0; u < 16; ++u) v[u] = buf[(rb + u) * RT2D_WAVE + lane];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) { S += v[u]; v[u] = S; }       // ray.py:347
 #pragma unroll
-                for (int u = 0; u < 16; ++u) s_buf[(rb + u) * RT2D_WAVE + lane] = v[u];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < GAIN_SCAN_PER_THREAD; ++k) {
-            const int sx = s_first + row0 + ROW_STEP * k;
-            if (sx < np) {
-                while (sx >= next_reb_at) {
-                    A = s_loss[next_reb * RT2D_WAVE + lane];
-                    ++next_reb;
-                    next_reb_at = (next_reb < nreb) ? s_at[next_reb * RT2D_WAVE + lane] : 0x7fffffff;
-                }
-                G[c0 + threadIdx.x + GAIN_SCAN_THREADS * k] = s_buf[threadIdx.x + GAIN_SCAN_THREADS * k] + A;
+                for (int u = 0; u < 16; ++u) buf[(rb + u) * RT2D_WAVE + lane] = v[u];
             }
         }
         __syncthreads();
@@ -2579,7 +2594,7 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     if (lds > RT2D_LDS_BUDGET) return fail("rt2d_gain: absorption tables do not fit in LDS");
     const int fch = n_freqs >= 8 ? 8 : (n_freqs >= 3 ? 4 : n_freqs);      // frequencies per lane: amortises the 6 table evals
     const char* tp = getenv("RT2D_GAIN_TWO_PHASE_MAX_RAYS");              // tests force either path with this
-    const size_t scan_lds = (size_t)GAIN_SCAN_ROWS * RT2D_WAVE * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * RT2D_WAVE * 12;
+    const size_t scan_lds = 3 * (size_t)GAIN_SCAN_ROWS * RT2D_WAVE * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * RT2D_WAVE * 12;
     // (measured crossovers: one frequency 65536 rays 1.40 -> 1.06 ms, 131072 rays 1.59 -> 1.96 ms; 65536 rays x 8
     // frequencies 4.8 -> 3.7 ms, x 64 frequencies slower again: the scan launches a workgroup per (tile, frequency))
     const bool two_phase = tp ? n <= atoll(tp) : (n <= 64 * 512 || (n <= 90000 && n * (int64_t)n_freqs <= 600000));
