@@ -526,14 +526,18 @@ __device__ __forceinline__ int rt2d_fit_code(const DevEnv& e, double x_prev, dou
 // clock) and where it ran; the destructor runs wherever the lane of the wave's first thread leaves the kernel.
 #ifndef RT2D_WAVE_LOG
 struct WaveLog { __device__ __forceinline__ WaveLog(const CastArgs&) {} };     // compiled out (costs four registers): -DRT2D_WAVE_LOG
+#define RT2D_WLOG(...)
 #else
 struct WaveLog {
     unsigned long long* slot; unsigned long long t0;
-    __device__ __forceinline__ WaveLog(const CastArgs& a) : slot(nullptr), t0(0) {
+    // steps the wave took in its tight loop / in the general loop, and the 100 MHz ticks spent in each
+    unsigned long long n_tight, n_general, ticks_tight, ticks_general;
+    unsigned long long clk_head, clk_tail;     // shader clocks of the tight loop: top -> decision, decision -> end of the step
+    __device__ __forceinline__ WaveLog(const CastArgs& a) : slot(nullptr), t0(0), n_tight(0), n_general(0), ticks_tight(0), ticks_general(0), clk_head(0), clk_tail(0) {
         if (a.wave_log == nullptr || (threadIdx.x & 63) != 0) return;
         const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         if (w >= a.wave_log_cap) return;
-        slot = a.wave_log + 4 * w;
+        slot = a.wave_log + 12 * w;
         t0 = __builtin_amdgcn_s_memrealtime();
     }
     __device__ __forceinline__ ~WaveLog() {
@@ -541,8 +545,11 @@ struct WaveLog {
         slot[0] = t0; slot[1] = __builtin_amdgcn_s_memrealtime();
         slot[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));          // HW_ID
         slot[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));         // XCC_ID
+        slot[4] = n_tight; slot[5] = n_general; slot[6] = ticks_tight; slot[7] = ticks_general;
+        slot[8] = clk_head; slot[9] = clk_tail;
     }
 };
+#define RT2D_WLOG(...) __VA_ARGS__
 #endif
 
 // WRITE: store the trajectory.  TAB: where the step tables are read from (see the kernel).
@@ -698,10 +705,12 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                                                 // attempt that takes no step (a wave of steep rays rebounds somewhere in
                                                 // almost every step and would pay for the attempt each time)
     for (; i < p.n_steps_max; ++i) {
+        RT2D_WLOG(const unsigned long long w_a = __builtin_amdgcn_s_memrealtime(); const int w_i = i;)
         if (tight_on && tight_wait > 0) --tight_wait;
         else if (tight_on) {
             const int i_in = i;
             while (i < p.n_steps_max - 1) {
+                RT2D_WLOG(const unsigned long long c_a = __builtin_amdgcn_s_memtime();)
                 const double kx_s = kx * p.dx_max, kz_s = kz * p.dx_max;          // ray.py:154 (not steep)
                 const double xn = x + kx_s, zn = z + kz_s;                         // ray.py:157
                 const double xa_t = vmin(vmax(xn, fl_lo), fl_hi);
@@ -736,6 +745,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                                   & (zn <= (CEILC ? z_hi_bound : vmin(z_hi_bound, zc_t)));
                 const bool plain_t = !(fabs(dx_z) > dx_z_max) & in_a & in_b & in_z & inside
                                    & (fabs(kx_s) == p.dx_max) & (fabs(kz_s) >= 1e-250) & (!WRITE | (n_pts < room));
+                RT2D_WLOG(const bool w_go = rt2d_all(plain_t); const unsigned long long c_b = __builtin_amdgcn_s_memtime();
+                          wave_log.clk_head += c_b - c_a; if (!w_go) break;)
                 if (!rt2d_all(plain_t)) break;
                 // commit (ray.py:235-247)
                 if (POST >= 1) { slope_max = vmax(slope_max, fabs(dx_z)); mono &= !(xn < x); }
@@ -756,10 +767,13 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 dx_z += dxdx_t * kx_s;
                 kx = x_dir; kz = dx_z;
                 ++i;
+                RT2D_WLOG(asm volatile("" :: "v"(kz)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
             }
             if (i == i_in) { tight_wait = tight_penalty; tight_penalty = min(2 * tight_penalty, 64); }
             else tight_penalty = 1;
         }
+        RT2D_WLOG(const unsigned long long w_b = __builtin_amdgcn_s_memrealtime();
+                  wave_log.ticks_tight += w_b - w_a; wave_log.n_tight += (unsigned long long)(i - w_i);)
         // step sizing (ray.py:153-154)
         const bool steep = fabs(dx_z) > dx_z_max;
         if (POST >= 1) slope_max = vmax(slope_max, fabs(dx_z));
@@ -949,6 +963,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
 
         if (__builtin_expect(!p.backprop && x_dir < 0, 0)) { stop = RT2D_STOP_BACKPROP; break; }   // ray.py:252-255
         if (i == p.n_steps_max - 1) stop = RT2D_STOP_MAX_ITER;                 // ray.py:257-259
+        RT2D_WLOG(wave_log.ticks_general += __builtin_amdgcn_s_memrealtime() - w_b; wave_log.n_general += 1ull;)
     }
 
     if (FUSE) {
