@@ -229,25 +229,21 @@ class Map:
                      'distance'  -> x = d * t, metres along the path (build-specific)
         Returns (x, z).
         """
-        p0 = np.deg2rad(start)
-        p1 = np.deg2rad(stop)
-        x0 = np.sin(p0[1]) * np.cos(p0[0])
-        y0 = np.sin(p0[1]) * np.sin(p0[0])
-        z0 = np.cos(p0[1])
-        x1 = np.sin(p1[1]) * np.cos(p1[0])
-        y1 = np.sin(p1[1]) * np.sin(p1[0])
-        z1 = np.cos(p1[1])
-        v0 = np.array([x0, y0, z0])
-        v1 = np.array([x1, y1, z1])
-        theta = np.arccos(np.dot(v0, v1))
+        ends = np.deg2rad(np.asarray([start, stop], dtype=np.float64))          # rows: (long, lat) in radians
 
-        d = theta * EARTH_RADIUS_AVG
+        def on_sphere(q):
+            # the reference's (non-standard) use of the latitude as polar angle, kept for its numbers
+            return np.array([np.sin(q[1]) * np.cos(q[0]), np.sin(q[1]) * np.sin(q[0]), np.cos(q[1])])
+
+        theta = np.arccos(np.dot(on_sphere(ends[0]), on_sphere(ends[1])))        # angle between the two end points
+        d = theta * EARTH_RADIUS_AVG                                             # path length in metres
         res = d / (npoints - 1)
 
+        # spherical linear interpolation of the (long, lat) pairs, weights sin(theta (1 - t)) and sin(theta t)
         t = np.linspace(0, 1, npoints)
-        u = np.sin(theta * (1 - t))
-        v = np.sin(theta * t)
-        p = (p0 * np.tile(u, (2, 1)).T + p1 * np.tile(v, (2, 1)).T) / np.sin(theta)
+        w_start = np.sin(theta * (1 - t))[:, None]
+        w_stop = np.sin(theta * t)[:, None]
+        p = (ends[0] * w_start + ends[1] * w_stop) / np.sin(theta)
 
         if axis == 'reference':
             x = res * t
@@ -269,14 +265,13 @@ class Map:
         x, z = self.cut(start, stop, npoints=npoints, axis=axis)
         return linear_interp_table(x, z, oob=OOB_CLAMP)
 
-    def display(self):
+    def display(self, ax=None, cmap='gray_r', nodata_color=(0.6, 0.3, 0.)):
+        """Depth picture of the grid, north up: shallow is light, deep is dark, cells without data in
+        ``nodata_color`` (what the reference's display shows; drawn here as one masked image with a colour map)."""
         import matplotlib.pyplot as plt
-        depth = np.copy(self.map_array)[:, ::-1]
-        depth[self._map_nan[:, ::-1]] = 0.
-        depth = 1. - (np.abs(depth) / np.amax(np.abs(depth)))
-        img = np.zeros((self.shape_x, self.shape_y, 3))
-        img[:, :, 0] = depth
-        img[:, :, 1] = depth
-        img[:, :, 2] = depth
-        img[self._map_nan[:, ::-1]] = [0.6, 0.3, 0.]
-        plt.imshow(np.transpose(img, (1, 0, 2)))
+        from matplotlib import colormaps
+        depth = np.ma.masked_invalid(np.abs(self.map_array.T[::-1]))            # back to file order: rows north to south
+        shades = colormaps[cmap].copy()
+        shades.set_bad(nodata_color)
+        ax = plt.gca() if ax is None else ax
+        return ax.imshow(depth, cmap=shades, vmin=0., vmax=float(depth.max()))
