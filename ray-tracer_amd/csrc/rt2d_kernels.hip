@@ -618,15 +618,23 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     const DevEnv& e = a.env;
     const Rt2dParams& p = a.p;
 
-    // trajectory slot of this lane: pointer to its current point, and how many points its tile has room for
-    double* px = nullptr; double* pz = nullptr; double* pc = nullptr;
+    // trajectory slot of this lane: its tile's start (one tile per wave: `lanes` is a power of two, so the start sits
+    // in scalar registers and one 32-bit byte offset per lane addresses X, Z and C alike) and how many points the tile has
+    // room for
+    double* tx_base = nullptr; double* tz_base = nullptr; double* tc_base = nullptr;
+    unsigned int p_off = 0;                    // byte offset of this lane's CURRENT point inside its tile
     int room = 0;
     if (WRITE) {
         const int64_t t0 = a.tile_off[r >> 6], t1 = a.tile_off[(r >> 6) + 1];
         room = (int)((t1 - t0) / RT2D_WAVE);
-        px = a.X + t0 + (r & 63); pz = a.Z + t0 + (r & 63);
-        if (a.C) pc = a.C + t0 + (r & 63);
+        const int64_t t0u = (int64_t)(((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(t0 >> 32)) << 32)
+                                      | (unsigned int)__builtin_amdgcn_readfirstlane((int)t0));
+        tx_base = a.X + t0u; tz_base = a.Z + t0u;
+        if (a.C) tc_base = a.C + t0u;
+        p_off = (unsigned int)(r & 63) * 8u;
     }
+    auto put = [](double* base, unsigned int off, double v) { *(double*)((char*)base + off) = v; };
+    constexpr unsigned int P_STEP = RT2D_WAVE * 8u;
 
     int status = RT2D_RAY_OK, stop = RT2D_STOP_NONE, n_reb = 0, n_pts = 1;
     double x = a.src_x, z = a.src_z;
@@ -656,9 +664,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     const bool has_target = FULL && p.has_target != 0;
     const double tx = p.target[0], tz = p.target[1];
     TargetTrack tt;
-    if (FULL || (WRITE && pc)) c_pt = rt2d_eval_c(tab_cz, e.cz, z);          // C[0] = calc_c(z0), ray.py:273
+    if (FULL || (WRITE && tc_base)) c_pt = rt2d_eval_c(tab_cz, e.cz, z);          // C[0] = calc_c(z0), ray.py:273
     if (FULL) { tt.init(); if (has_target) tt.add(x, z, 0.0, 0, tx); }
-    if (WRITE && room > 0) { *px = x; *pz = z; if (pc) *pc = c_pt; }
+    if (WRITE && room > 0) { put(tx_base, p_off, x); put(tz_base, p_off, z); if (tc_base) put(tc_base, p_off, c_pt); }
     // running gain at the cut-off frequency
     double g_S = 0.0, g_A = 0.0, g_pend = 0.0, g_ff = 0.0;
     const double* gtab = a.blob + e.gain_off;
@@ -676,8 +684,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // operand and quiet a NaN result, which is what fmax / fmin do.
     auto vmax = [](double u, double v) -> double { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v)); return r; };
     auto vmin = [](double u, double v) -> double { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v)); return r; };
-    const double fl_jmax = (double)(e.floor.n_pieces - 1), ce_jmax = (double)(e.ceil.n_pieces - 1);
-    const double cz_jmax = (double)(e.cz.n_pieces - 1);
+    auto vmax_abs = [](double u, double v) -> double { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(u), "v"(v)); return r; };   // max(u, |v|)
+    const int fl_jmax = e.floor.n_pieces - 1, ce_jmax = e.ceil.n_pieces - 1;
+    const int cz_jmax = e.cz.n_pieces - 1;
     // the bounds those instructions take, parked in vector registers for the whole loop (the empty asm keeps the compiler
     // from re-creating them from scalar registers in front of every use)
     double fl_lo = e.floor.lo, fl_hi = e.floor.hi, ce_lo = e.ceil.lo, ce_hi = e.ceil.hi;
@@ -685,9 +694,63 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     if (CEILC) z_hi_bound = vmin(z_hi_bound, a.ceil_const);
     asm volatile("" : "+v"(fl_lo), "+v"(fl_hi), "+v"(z_lo_bound), "+v"(z_hi_bound));
     if (!CEILC) asm volatile("" : "+v"(ce_lo), "+v"(ce_hi));
-    auto guess = [&](const DevTable& t, double v, double jmax) -> int {     // rt2d_guess
-        double g = (v - t.x0) * t.inv_h;
-        return (int)vmin(vmax(g, 0.0), jmax);                               // NaN -> 0 through the max
+    // rt2d_guess with the clamp on the integer side: v_cvt_i32_f64 saturates and turns a NaN into 0, so the piece is the
+    // same for every input (fewer instructions than the max / min pair in double and the idle cycles behind each of them)
+    auto guess = [&](const DevTable& t, double v, int jmax) -> int {
+        const double g = (v - t.x0) * t.inv_h;
+        int j;
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(j) : "v"(g));
+        return min(max(j, 0), jmax);
+    };
+    // the same with the clamp to [j_lo, j_hi] in one instruction (j_lo <= j_hi; j_hi in a vector register)
+    auto guess_in = [&](const DevTable& t, double v, int j_lo, int j_hi) -> int {
+        const double g = (v - t.x0) * t.inv_h;
+        int j;
+        asm("v_cvt_i32_f64 %0, %1\n\tv_med3_i32 %0, %0, %2, %3" : "=&v"(j) : "v"(g), "s"(j_lo), "v"(j_hi));
+        return j;
+    };
+    // Lane masks of single comparisons as 64-bit scalars (a bit is set for an enabled lane whose comparison holds, as the
+    // comparison of the source language would be: an unordered pair fails ge / lt / le and passes ngt): combined with
+    // scalar AND and tested against the mask of enabled lanes in one instruction, where the compiler's own lowering of
+    // "all lanes" goes back through a vector register.
+    auto m_ge = [](double u, double v) -> unsigned long long { unsigned long long m; asm("v_cmp_ge_f64 %0, %1, %2" : "=s"(m) : "v"(u), "v"(v)); return m; };
+    auto m_lt = [](double u, double v) -> unsigned long long { unsigned long long m; asm("v_cmp_lt_f64 %0, %1, %2" : "=s"(m) : "v"(u), "v"(v)); return m; };
+    auto m_le = [](double u, double v) -> unsigned long long { unsigned long long m; asm("v_cmp_le_f64 %0, %1, %2" : "=s"(m) : "v"(u), "v"(v)); return m; };
+    auto m_abs_ngt = [](double u, double v) -> unsigned long long { unsigned long long m; asm("v_cmp_ngt_f64 %0, |%1|, %2" : "=s"(m) : "v"(u), "v"(v)); return m; };
+    // (second operand wave-uniform, taken from a scalar register pair)
+    auto m_abs_ge = [](double u, double v) -> unsigned long long { unsigned long long m; asm("v_cmp_ge_f64 %0, |%1|, %2" : "=s"(m) : "v"(u), "s"(v)); return m; };
+
+    // Record fetches.  Where the table is staged in LDS the record's byte address is ONE 24-bit multiply-add on a scalar
+    // base (a piece index is far below 2^24; the generic pointers above cost a move and a 64-bit multiply-add each).
+    typedef const __attribute__((address_space(3))) double lds_cdouble;
+    constexpr bool FL_LDS = (TAB == 1) || (TAB == 2 && FUSE != 0);
+    constexpr bool CZ_LDS = (TAB != 0);
+    const unsigned int l_base = (unsigned int)(size_t)(lds_cdouble*)s_tab;
+    auto load_fl = [&](const DevTable& t, int j, double (&rr)[4]) {
+        if constexpr (FL_LDS) {
+            unsigned int addr;
+            asm("v_mad_u32_u24 %0, %1, 24, %2" : "=v"(addr) : "v"(j), "s"(l_base + (unsigned int)t.off * 8u));
+            lds_cdouble* q = (lds_cdouble*)(size_t)addr;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[k] = q[k];
+        } else {
+            auto q = tab_fl + t.off + j * 3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[k] = q[k];
+        }
+    };
+    auto load_cz = [&](const DevTable& t, int j, double (&rr)[8]) {
+        if constexpr (CZ_LDS) {
+            unsigned int addr;
+            asm("v_mad_u32_u24 %0, %1, 56, %2" : "=v"(addr) : "v"(j), "s"(l_base + (unsigned int)t.off * 8u));
+            lds_cdouble* q = (lds_cdouble*)(size_t)addr;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rr[k] = q[k];
+        } else {
+            auto q = tab_cz + t.off + j * 7;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rr[k] = q[k];
+        }
     };
 
     // Plain steps: a step of dx_max (ray not steep) whose point is inside the rectangle, between floor and surface, with
@@ -699,7 +762,42 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // untouched for the general loop, which then tries the tight loop again.  (The waves of a small fan hold four shallow
     // rays that rebound twenty times in 1500 steps: they spend nine steps in ten here.)
     constexpr bool TIGHT = (POST <= 1) && !CUTOFF && (FUSE == 0);
-    const bool tight_on = TIGHT && !(WRITE && a.C != nullptr);
+    bool tight_on = TIGHT && !(WRITE && a.C != nullptr);
+    // Wave-uniform facts the tight loop leans on, established once:
+    //  - every guessed piece is verified against its two breaks, which needs the uniform-grid hint of all three tables;
+    //  - the guesses are clamped to the pieces that lie WHOLLY inside the rectangle (floor pieces in x, sound-speed
+    //    pieces in z): a point verified to be in its guessed piece is then inside the rectangle without a comparison
+    //    against the rectangle, and a point in a piece that straddles the border fails the verification and is left to
+    //    the general step;
+    //  - the lanes of a wave share their tile's room, and a ray has at most i + 1 points before step i: step i fits
+    //    while i + 1 < room, one scalar comparison instead of a per-lane one.
+    tight_on = tight_on && e.floor.uniform != 0 && e.cz.uniform != 0 && (CEILC || e.ceil.uniform != 0);
+    int fl_j0 = 0, fl_j1 = fl_jmax, cz_j0 = 0, cz_j1 = cz_jmax;
+    if (TIGHT) {
+        auto pieces_inside = [](auto tab, const DevTable& t, double lo, double hi, int& j0, int& j1) {
+            int j = rt2d_fix_piece(tab, t, lo, rt2d_guess(t, lo));                 // last piece that starts at or below lo
+            j0 = (tab[t.off + j * t.stride] >= lo) ? j : j + 1;
+            j = rt2d_fix_piece(tab, t, hi, rt2d_guess(t, hi));
+            j1 = (tab[t.off + (j + 1) * t.stride] <= hi) ? j : j - 1;
+            j0 = __builtin_amdgcn_readfirstlane(j0); j1 = __builtin_amdgcn_readfirstlane(j1);
+        };
+        if (!((e.floor.lo >= e.range_min[0]) && (e.floor.hi <= e.range_max[0])))
+            pieces_inside(tab_fl, e.floor, e.range_min[0], e.range_max[0], fl_j0, fl_j1);
+        const double z_top = CEILC ? fmin(e.range_max[1], a.ceil_const) : e.range_max[1];
+        if (!((e.cz.lo >= e.range_min[1]) && (e.cz.hi <= z_top)))
+            pieces_inside(tab_cz, e.cz, e.range_min[1], z_top, cz_j0, cz_j1);
+        tight_on = tight_on && fl_j0 <= fl_j1 && cz_j0 <= cz_j1;
+    }
+    int tight_end = p.n_steps_max - 1;
+    if (WRITE) {
+        const int room_u = __builtin_amdgcn_readfirstlane(room);
+        tight_on = tight_on && rt2d_all(room == room_u);
+        tight_end = min(tight_end, room_u - 1);
+    }
+    double dx_z_max_v = dx_z_max;
+    int fl_j1_v = fl_j1, cz_j1_v = cz_j1, ce_j1_v = ce_jmax;
+    asm volatile("" : "+v"(dx_z_max_v), "+v"(fl_j1_v), "+v"(cz_j1_v));
+    if (!CEILC) asm volatile("" : "+v"(ce_j1_v));
     int i = 0;
     int tight_wait = 0, tight_penalty = 1;      // wave-uniform: steps until the tight loop is tried again, doubled by every
                                                 // attempt that takes no step (a wave of steep rays rebounds somewhere in
@@ -709,68 +807,69 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         if (tight_on && tight_wait > 0) --tight_wait;
         else if (tight_on) {
             const int i_in = i;
-            while (i < p.n_steps_max - 1) {
+            // Through plain steps kx stays x_dir = +-1 (ray.py:242-246 give it back unchanged), so the step in x, its
+            // sign and "is it a whole dx_max" are fixed for the attempt; x moves one way, so the ends of the stretch
+            // give the bounding box in x and whether the ray turned back; kz is dx_z at the top of every step.
+            const double kx_s = kx * p.dx_max;                                    // ray.py:154 (not steep)
+            const double x_in = x;
+            const unsigned int flip = (kx_s < 0.0) ? 0x80000000u : 0u;           // k1/k0 changes sign with k0
+            const unsigned long long lanes_on = __builtin_amdgcn_read_exec();
+            // The loop is written rotated -- examine a step, then { commit it; examine the next } while it is plain -- so that
+            // an iteration ends in its one conditional branch.
+            double kz_s, xn, zn, tz8[8];
+            auto examine = [&]() -> bool {
                 RT2D_WLOG(const unsigned long long c_a = __builtin_amdgcn_s_memtime();)
-                const double kx_s = kx * p.dx_max, kz_s = kz * p.dx_max;          // ray.py:154 (not steep)
-                const double xn = x + kx_s, zn = z + kz_s;                         // ray.py:157
-                const double xa_t = vmin(vmax(xn, fl_lo), fl_hi);
-                const double xb_t = CEILC ? 0.0 : vmin(vmax(xn, ce_lo), ce_hi);
-                const int ja_t = guess(e.floor, xa_t, fl_jmax), jb_t = CEILC ? 0 : guess(e.ceil, xb_t, ce_jmax);
-                const int jz_t = guess(e.cz, zn, cz_jmax);
-                double ta[4], tb[4], tz8[8];
-                {
-                    auto pa = tab_fl + e.floor.off + ja_t * 3;
-                    auto pzr = tab_cz + e.cz.off + jz_t * 7;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) ta[k] = pa[k];
-                    if (!CEILC) {
-                        auto pb = tab_fl + e.ceil.off + jb_t * 3;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) tb[k] = pb[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) tz8[k] = pzr[k];
-                }
+                kz_s = dx_z * p.dx_max;
+                xn = x + kx_s; zn = z + kz_s;                                      // ray.py:157
+                // (no clamp of xn into the tables: a point outside them is in no piece and fails below)
+                const int ja_t = guess_in(e.floor, xn, fl_j0, fl_j1_v), jb_t = CEILC ? 0 : guess_in(e.ceil, xn, 0, ce_j1_v);
+                const int jz_t = guess_in(e.cz, zn, cz_j0, cz_j1_v);
+                double ta[4], tb[4];
+                load_fl(e.floor, ja_t, ta);
+                if (!CEILC) load_fl(e.ceil, jb_t, tb);
+                load_cz(e.cz, jz_t, tz8);
                 // (every word of the three records is wanted HERE: without this the compiler sinks the loads of the
                 // coefficients behind the exit test below, a second LDS round trip on the critical path of every step)
                 asm volatile("" :: "v"(ta[1]), "v"(ta[2]), "v"(tz8[1]), "v"(tz8[2]), "v"(tz8[3]), "v"(tz8[4]), "v"(tz8[5]), "v"(tz8[6]));
                 // the guessed pieces must be the right ones WITHOUT the end-piece exceptions of the general step (a point in
                 // an end piece that fails here is simply left to the general step)
-                const bool in_a = (xa_t >= ta[0]) & (xa_t < ta[3]) & (e.floor.uniform != 0);
-                const bool in_b = CEILC ? true : ((xb_t >= tb[0]) & (xb_t < tb[3]) & (e.ceil.uniform != 0));
-                const bool in_z = (zn >= tz8[0]) & (zn < tz8[7]) & (e.cz.uniform != 0);
-                const double zf_t = ta[1] * (xa_t - ta[0]) + ta[2];
-                const double zc_t = CEILC ? a.ceil_const : tb[1] * (xb_t - tb[0]) + tb[2];
-                const bool inside = (xn >= e.range_min[0]) & (xn <= e.range_max[0]) & (zn >= vmax(z_lo_bound, zf_t))
-                                  & (zn <= (CEILC ? z_hi_bound : vmin(z_hi_bound, zc_t)));
-                const bool plain_t = !(fabs(dx_z) > dx_z_max) & in_a & in_b & in_z & inside
-                                   & (fabs(kx_s) == p.dx_max) & (fabs(kz_s) >= 1e-250) & (!WRITE | (n_pts < room));
-                RT2D_WLOG(const bool w_go = rt2d_all(plain_t); const unsigned long long c_b = __builtin_amdgcn_s_memtime();
-                          wave_log.clk_head += c_b - c_a; if (!w_go) break;)
-                if (!rt2d_all(plain_t)) break;
+                const double zf_t = ta[1] * (xn - ta[0]) + ta[2];
+                unsigned long long ok_t = m_ge(xn, ta[0]) & m_lt(xn, ta[3]) & m_ge(zn, tz8[0]) & m_lt(zn, tz8[7])
+                                        & m_ge(zn, zf_t) & m_abs_ngt(dx_z, dx_z_max_v) & m_abs_ge(kz_s, 1e-250);
+                if (!CEILC) {
+                    const double zc_t = tb[1] * (xn - tb[0]) + tb[2];
+                    ok_t &= m_ge(xn, tb[0]) & m_lt(xn, tb[3]) & m_le(zn, zc_t);
+                }
+                RT2D_WLOG(wave_log.clk_head += __builtin_amdgcn_s_memtime() - c_a;)
+                // plain for every ray, and the step count / the tile's room not at their end
+                const unsigned long long go_t = (i < tight_end) ? ok_t : 0ull;
+                return (lanes_on & ~go_t) == 0ull;
+            };
+            if (rt2d_all(fabs(kx_s) == p.dx_max) && examine())
+            do {
+                RT2D_WLOG(const unsigned long long c_b = __builtin_amdgcn_s_memtime();)
                 // commit (ray.py:235-247)
-                if (POST >= 1) { slope_max = vmax(slope_max, fabs(dx_z)); mono &= !(xn < x); }
+                if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
                 x = xn; z = zn;
                 const double dzr_t = z - tz8[0];
                 c = rt2d_quad_of(tz8, dzr_t, 0);
                 const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
-                if (POST >= 1) {
-                    min_x = vmin(min_x, x); max_x = vmax(max_x, x);
-                    min_z = vmin(min_z, z); max_z = vmax(max_z, z);
-                }
-                if (WRITE) { px += RT2D_WAVE; pz += RT2D_WAVE; *px = x; *pz = z; }
-                n_pts += 1;
-                x_dir = rt2d_sign(kx_s);
+                if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
+                if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
                 const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);      // k1/k0 (ray.py:243)
-                dx_z = (kx_s < 0.0) ? -1 * q_t : q_t;
+                dx_z = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_t) ^ ((unsigned long long)flip << 32)));
                 const double dxdx_t = mult * dz_c_t / (c * c * c);
                 dx_z += dxdx_t * kx_s;
-                kx = x_dir; kz = dx_z;
                 ++i;
-                RT2D_WLOG(asm volatile("" :: "v"(kz)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
-            }
+                RT2D_WLOG(asm volatile("" :: "v"(dx_z)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
+            } while (examine());
+            kz = dx_z;
+            n_pts += i - i_in;
             if (i == i_in) { tight_wait = tight_penalty; tight_penalty = min(2 * tight_penalty, 64); }
-            else tight_penalty = 1;
+            else {
+                tight_penalty = 1;
+                if (POST >= 1) { mono &= !(x < x_in); min_x = vmin(min_x, x); max_x = vmax(max_x, x); }
+            }
         }
         RT2D_WLOG(const unsigned long long w_b = __builtin_amdgcn_s_memrealtime();
                   wave_log.ticks_tight += w_b - w_a; wave_log.n_tight += (unsigned long long)(i - w_i);)
@@ -797,19 +896,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         int ja = guess(e.floor, xa, fl_jmax), jb = CEILC ? 0 : guess(e.ceil, xb, ce_jmax);
         const int jz = guess(e.cz, z_new, cz_jmax);
         double ra[4], rb[4], rz[8];
-        {
-            auto pa = tab_fl + e.floor.off + ja * 3;
-            auto pzr = tab_cz + e.cz.off + jz * 7;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ra[k] = pa[k];
-            if (!CEILC) {
-                auto pb = tab_fl + e.ceil.off + jb * 3;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) rb[k] = pb[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) rz[k] = pzr[k];
-        }
+        load_fl(e.floor, ja, ra);
+        if (!CEILC) load_fl(e.ceil, jb, rb);
+        load_cz(e.cz, jz, rz);
         // The common step -- inside the rectangle, between floor and surface, all three guessed pieces right -- is
         // recognised by ONE predicate and skips every branch of the general case below; when the predicate fails the
         // general case runs in the reference's order (ray.py:162-230) and none of its branches would fire otherwise.
@@ -939,9 +1028,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         }
         if (FULL && has_target) tt.add(x, z, T, n_pts, tx);
         if (WRITE && __builtin_expect(n_pts < room, 1)) {
-            px += RT2D_WAVE; pz += RT2D_WAVE;
-            *px = x; *pz = z;
-            if (__builtin_expect(a.C != nullptr, 0)) { pc += RT2D_WAVE; *pc = c; }     // uniform test: no per-lane branch to skip
+            p_off += P_STEP;
+            put(tx_base, p_off, x); put(tz_base, p_off, z);
+            if (__builtin_expect(a.C != nullptr, 0)) put(tc_base, p_off, c);           // uniform test: no per-lane branch to skip
         }
         n_pts += 1;
         if (FUSE) binner.point(a.bin, x, z, g_pt, lane);
