@@ -13,6 +13,7 @@
 // Compiled with -ffp-contract=off: every expression is evaluated exactly as written, which is what makes the
 // trajectories comparable bit for bit with the CPU oracle (oracle/rt2d_oracle.c).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -533,6 +534,7 @@ struct WaveLog {
     // steps the wave took in its tight loop / in the general loop, and the 100 MHz ticks spent in each
     unsigned long long n_tight, n_general, ticks_tight, ticks_general;
     unsigned long long clk_head, clk_tail;     // shader clocks of the tight loop: top -> decision, decision -> end of the step
+    unsigned long long n_gen_flag = 0, n_gen_steep = 0;    // general iterations in which some ray left the common step / was steep
     __device__ __forceinline__ WaveLog(const CastArgs& a) : slot(nullptr), t0(0), n_tight(0), n_general(0), ticks_tight(0), ticks_general(0), clk_head(0), clk_tail(0) {
         if (a.wave_log == nullptr || (threadIdx.x & 63) != 0) return;
         const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -546,7 +548,7 @@ struct WaveLog {
         slot[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));          // HW_ID
         slot[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));         // XCC_ID
         slot[4] = n_tight; slot[5] = n_general; slot[6] = ticks_tight; slot[7] = ticks_general;
-        slot[8] = clk_head; slot[9] = clk_tail;
+        slot[8] = clk_head; slot[9] = clk_tail; slot[10] = n_gen_flag; slot[11] = n_gen_steep;
     }
 };
 #define RT2D_WLOG(...) __VA_ARGS__
@@ -766,9 +768,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // Wave-uniform facts the tight loop leans on, established once:
     //  - every guessed piece is verified against its two breaks, which needs the uniform-grid hint of all three tables;
     //  - the guesses are clamped to the pieces that lie WHOLLY inside the rectangle (floor pieces in x, sound-speed
-    //    pieces in z): a point verified to be in its guessed piece is then inside the rectangle without a comparison
-    //    against the rectangle, and a point in a piece that straddles the border fails the verification and is left to
-    //    the general step;
+    //    pieces at the lower end in z): a point verified to be in its guessed piece is then inside the rectangle without
+    //    a comparison against the rectangle, and a point in a piece that straddles the border fails the verification and
+    //    is left to the general step;
     //  - the lanes of a wave share their tile's room, and a ray has at most i + 1 points before step i: step i fits
     //    while i + 1 < room, one scalar comparison instead of a per-lane one.
     tight_on = tight_on && e.floor.uniform != 0 && e.cz.uniform != 0 && (CEILC || e.ceil.uniform != 0);
@@ -783,9 +785,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         };
         if (!((e.floor.lo >= e.range_min[0]) && (e.floor.hi <= e.range_max[0])))
             pieces_inside(tab_fl, e.floor, e.range_min[0], e.range_max[0], fl_j0, fl_j1);
-        const double z_top = CEILC ? fmin(e.range_max[1], a.ceil_const) : e.range_max[1];
-        if (!((e.cz.lo >= e.range_min[1]) && (e.cz.hi <= z_top)))
-            pieces_inside(tab_cz, e.cz, e.range_min[1], z_top, cz_j0, cz_j1);
+        // (in z only the lower side: the sound-speed table usually reaches above the surface, and the rays of a surface
+        // duct spend their time in its top piece -- the upper bound keeps its comparison)
+        if (!(e.cz.lo >= e.range_min[1])) pieces_inside(tab_cz, e.cz, e.range_min[1], e.cz.hi, cz_j0, cz_j1);
         tight_on = tight_on && fl_j0 <= fl_j1 && cz_j0 <= cz_j1;
     }
     int tight_end = p.n_steps_max - 1;
@@ -807,65 +809,89 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         if (tight_on && tight_wait > 0) --tight_wait;
         else if (tight_on) {
             const int i_in = i;
-            // Through plain steps kx stays x_dir = +-1 (ray.py:242-246 give it back unchanged), so the step in x, its
-            // sign and "is it a whole dx_max" are fixed for the attempt; x moves one way, so the ends of the stretch
-            // give the bounding box in x and whether the ray turned back; kz is dx_z at the top of every step.
-            const double kx_s = kx * p.dx_max;                                    // ray.py:154 (not steep)
+            // Through such steps kx stays x_dir = +-1 (ray.py:242-246 give it back unchanged): x moves one way, so the ends of
+            // the stretch give the bounding box in x and whether the ray turned back; kz is dx_z at the top of every step.
+            // Two forms of the loop.  PLAIN: no ray is steep -- the step in x is +-dx_max for the whole stretch, k1/k0 is a
+            // division by that constant.  STEEP (some ray is steep, ray.py:153): the step length is chosen per ray
+            // (dz_max / |dx_z| for a steep one) and k1/k0 is the IEEE division; it ends when no ray is steep any more.
             const double x_in = x;
-            const unsigned int flip = (kx_s < 0.0) ? 0x80000000u : 0u;           // k1/k0 changes sign with k0
             const unsigned long long lanes_on = __builtin_amdgcn_read_exec();
-            // The loop is written rotated -- examine a step, then { commit it; examine the next } while it is plain -- so that
-            // an iteration ends in its one conditional branch.
-            double kz_s, xn, zn, tz8[8];
-            auto examine = [&]() -> bool {
-                RT2D_WLOG(const unsigned long long c_a = __builtin_amdgcn_s_memtime();)
-                kz_s = dx_z * p.dx_max;
-                xn = x + kx_s; zn = z + kz_s;                                      // ray.py:157
-                // (no clamp of xn into the tables: a point outside them is in no piece and fails below)
-                const int ja_t = guess_in(e.floor, xn, fl_j0, fl_j1_v), jb_t = CEILC ? 0 : guess_in(e.ceil, xn, 0, ce_j1_v);
-                const int jz_t = guess_in(e.cz, zn, cz_j0, cz_j1_v);
-                double ta[4], tb[4];
-                load_fl(e.floor, ja_t, ta);
-                if (!CEILC) load_fl(e.ceil, jb_t, tb);
-                load_cz(e.cz, jz_t, tz8);
-                // (every word of the three records is wanted HERE: without this the compiler sinks the loads of the
-                // coefficients behind the exit test below, a second LDS round trip on the critical path of every step)
-                asm volatile("" :: "v"(ta[1]), "v"(ta[2]), "v"(tz8[1]), "v"(tz8[2]), "v"(tz8[3]), "v"(tz8[4]), "v"(tz8[5]), "v"(tz8[6]));
-                // the guessed pieces must be the right ones WITHOUT the end-piece exceptions of the general step (a point in
-                // an end piece that fails here is simply left to the general step)
-                const double zf_t = ta[1] * (xn - ta[0]) + ta[2];
-                unsigned long long ok_t = m_ge(xn, ta[0]) & m_lt(xn, ta[3]) & m_ge(zn, tz8[0]) & m_lt(zn, tz8[7])
-                                        & m_ge(zn, zf_t) & m_abs_ngt(dx_z, dx_z_max_v) & m_abs_ge(kz_s, 1e-250);
-                if (!CEILC) {
-                    const double zc_t = tb[1] * (xn - tb[0]) + tb[2];
-                    ok_t &= m_ge(xn, tb[0]) & m_lt(xn, tb[3]) & m_le(zn, zc_t);
-                }
-                RT2D_WLOG(wave_log.clk_head += __builtin_amdgcn_s_memtime() - c_a;)
-                // plain for every ray, and the step count / the tile's room not at their end
-                const unsigned long long go_t = (i < tight_end) ? ok_t : 0ull;
-                return (lanes_on & ~go_t) == 0ull;
+            auto stretch = [&](auto steep_form) {
+                constexpr bool ST = decltype(steep_form)::value;
+                const double kx_p = kx * p.dx_max;                                // ray.py:154 (not steep)
+                const unsigned int flip = (kx_p < 0.0) ? 0x80000000u : 0u;       // k1/k0 changes sign with k0
+                // The loop is written rotated -- examine a step, then { commit it; examine the next } while it can be taken
+                // -- so that an iteration ends in its one conditional branch.
+                double kx_s = kx_p, kz_s, xn, zn, tz8[8];
+                auto examine = [&]() -> bool {
+                    RT2D_WLOG(const unsigned long long c_a = __builtin_amdgcn_s_memtime();)
+                    unsigned long long steep_t = 0ull;
+                    if (ST) {
+                        const double ss = p.dz_max / fabs(dx_z);                   // ray.py:153
+                        const bool st = fabs(dx_z) > dx_z_max;
+                        steep_t = __builtin_amdgcn_ballot_w64(st);
+                        const double sl = st ? ss : p.dx_max;
+                        kx_s = kx * sl; kz_s = dx_z * sl;
+                    } else {
+                        kz_s = dx_z * p.dx_max;
+                    }
+                    xn = x + kx_s; zn = z + kz_s;                                  // ray.py:157
+                    // (no clamp of xn into the tables: a point outside them is in no piece and fails below)
+                    const int ja_t = guess_in(e.floor, xn, fl_j0, fl_j1_v), jb_t = CEILC ? 0 : guess_in(e.ceil, xn, 0, ce_j1_v);
+                    const int jz_t = guess_in(e.cz, zn, cz_j0, cz_j1_v);
+                    double ta[4], tb[4];
+                    load_fl(e.floor, ja_t, ta);
+                    if (!CEILC) load_fl(e.ceil, jb_t, tb);
+                    load_cz(e.cz, jz_t, tz8);
+                    // (every word of the three records is wanted HERE: without this the compiler sinks the loads of the
+                    // coefficients behind the exit test below, a second LDS round trip on the critical path of every step)
+                    asm volatile("" :: "v"(ta[1]), "v"(ta[2]), "v"(tz8[1]), "v"(tz8[2]), "v"(tz8[3]), "v"(tz8[4]), "v"(tz8[5]), "v"(tz8[6]));
+                    // the guessed pieces must be the right ones WITHOUT the end-piece exceptions of the general step (a point
+                    // in an end piece that fails here is simply left to the general step)
+                    const double zf_t = ta[1] * (xn - ta[0]) + ta[2];
+                    unsigned long long ok_t = m_ge(xn, ta[0]) & m_lt(xn, ta[3]) & m_ge(zn, tz8[0]) & m_lt(zn, tz8[7]) & m_ge(zn, zf_t);
+                    if (!ST) ok_t &= m_abs_ngt(dx_z, dx_z_max_v) & m_abs_ge(kz_s, 1e-250);
+                    if (CEILC) {
+                        ok_t &= m_le(zn, z_hi_bound);
+                    } else {
+                        const double zc_t = tb[1] * (xn - tb[0]) + tb[2];
+                        ok_t &= m_ge(xn, tb[0]) & m_lt(xn, tb[3]) & m_le(zn, vmin(z_hi_bound, zc_t));
+                    }
+                    RT2D_WLOG(wave_log.clk_head += __builtin_amdgcn_s_memtime() - c_a;)
+                    // every ray can take the step as it stands, and the step count / the tile's room are not at their end
+                    const unsigned long long go_t = ((i < tight_end) & (!ST | (steep_t != 0ull))) ? ok_t : 0ull;
+                    return (lanes_on & ~go_t) == 0ull;
+                };
+                if (examine())
+                do {
+                    RT2D_WLOG(const unsigned long long c_b = __builtin_amdgcn_s_memtime();)
+                    // commit (ray.py:235-247)
+                    if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
+                    x = xn; z = zn;
+                    const double dzr_t = z - tz8[0];
+                    c = rt2d_quad_of(tz8, dzr_t, 0);
+                    const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
+                    if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
+                    if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
+                    if (ST) {
+                        dx_z = kz_s / kx_s;                                               // k1/k0 (ray.py:243)
+                    } else {
+                        const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);
+                        dx_z = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_t) ^ ((unsigned long long)flip << 32)));
+                    }
+                    const double dxdx_t = mult * dz_c_t / (c * c * c);
+                    dx_z += dxdx_t * kx_s;
+                    ++i;
+                    RT2D_WLOG(asm volatile("" :: "v"(dx_z)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
+                } while (examine());
             };
-            if (rt2d_all(fabs(kx_s) == p.dx_max) && examine())
-            do {
-                RT2D_WLOG(const unsigned long long c_b = __builtin_amdgcn_s_memtime();)
-                // commit (ray.py:235-247)
-                if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
-                x = xn; z = zn;
-                const double dzr_t = z - tz8[0];
-                c = rt2d_quad_of(tz8, dzr_t, 0);
-                const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
-                if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
-                if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
-                const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);      // k1/k0 (ray.py:243)
-                dx_z = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_t) ^ ((unsigned long long)flip << 32)));
-                const double dxdx_t = mult * dz_c_t / (c * c * c);
-                dx_z += dxdx_t * kx_s;
-                ++i;
-                RT2D_WLOG(asm volatile("" :: "v"(dx_z)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
-            } while (examine());
+            if (rt2d_all(fabs(kx) == 1.0)) {
+                stretch(std::false_type{});
+                if (rt2d_any(fabs(dx_z) > dx_z_max)) stretch(std::true_type{});
+            }
             kz = dx_z;
             n_pts += i - i_in;
-            if (i == i_in) { tight_wait = tight_penalty; tight_penalty = min(2 * tight_penalty, 64); }
+            if (i == i_in) { tight_wait = tight_penalty - 1; tight_penalty = min(2 * tight_penalty, 64); }
             else {
                 tight_penalty = 1;
                 if (POST >= 1) { mono &= !(x < x_in); min_x = vmin(min_x, x); max_x = vmax(max_x, x); }
@@ -916,6 +942,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         bool final_pt = false;                 // the point about to be accepted is the ray's last (max-rebounds)
         // (branch hints: a wave alone on its CU pays an instruction-fetch stall at every taken branch, so the common
         // step should be laid out as straight-line code)
+        RT2D_WLOG(if (rt2d_any(general)) wave_log.n_gen_flag += 1ull; if (rt2d_any(steep)) wave_log.n_gen_steep += 1ull;)
         if (__builtin_expect(rt2d_any(general), 0)) if (general) {
             if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point

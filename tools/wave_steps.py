@@ -35,10 +35,10 @@ lg = lg[lg[:, 1] > 0]
 dur = (lg[:, 1] - lg[:, 0]) / 100.
 print(f'{len(lg)} waves, kernel span {(lg[:, 1].max() - lg[:, 0].min()) / 100.:.0f} us, longest wave {dur.max():.0f} us')
 order = np.argsort(-dur)
-print('wave  dur_us  tight_steps  general_iters  us_tight  us_general  ns/tight_step  ns/general_iter')
+print('wave  dur_us  tight_steps  general_iters  us_tight  us_general  ns/tight_step  ns/general_iter  general: some ray off the common step / some ray steep')
 for w in list(order[:8]) + list(order[len(order) // 2: len(order) // 2 + 3]):
     nt, ng, tt, tg = lg[w, 4], lg[w, 5], lg[w, 6] / 100., lg[w, 7] / 100.
-    print(f'{w:5d} {dur[w]:7.0f} {nt:11d} {ng:13d} {tt:9.0f} {tg:11.0f} {1e3 * tt / max(nt, 1):13.0f} {1e3 * tg / max(ng, 1):15.0f}')
+    print(f'{w:5d} {dur[w]:7.0f} {nt:11d} {ng:13d} {tt:9.0f} {tg:11.0f} {1e3 * tt / max(nt, 1):13.0f} {1e3 * tg / max(ng, 1):15.0f} {lg[w, 10]:8d} {lg[w, 11]:8d}')
 nt, ng, tt, tg = lg[:, 4].sum(), lg[:, 5].sum(), lg[:, 6].sum() / 100., lg[:, 7].sum() / 100.
 print(f'tight loop, shader clocks per step: head (update, guesses, LDS, decision) {lg[:, 8].sum() / max(nt, 1):.0f}, tail (commit, division) {lg[:, 9].sum() / max(nt, 1):.0f}')
 print(f'all waves: {nt} tight steps in {tt:.0f} wave-us ({1e3 * tt / nt:.0f} ns each), {ng} general iterations in {tg:.0f} wave-us ({1e3 * tg / ng:.0f} ns each)')
