@@ -986,16 +986,29 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 kx = rx; kz = rzz;
                 double q = kz / kx;
                 double ang = 1 / sqrt(1 + q * q);                              // ray.py:184,207 (cos of grazing angle)
+                // What the rest of the branch needs from the parked launch data, fetched from LDS in ONE batch (read where
+                // they are used, each of the eight costs its own LDS round trip).  The log's addresses are device memory:
+                // as the generic pointers they are parked as, the stores would be FLAT instructions.
                 const Rt2dRayOut& co = cold->out;
-                if (n_reb < cold->rebound_cap) {
-                    int64_t k = (int64_t)n_reb * cold->n + r;
-                    if (co.reb_step) co.reb_step[k] = i + 1;
-                    if (co.reb_surface) co.reb_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
-                    if (co.reb_velocity) co.reb_velocity[k] = c;
-                    if (co.reb_angle) co.reb_angle[k] = ang;
-                    if (co.reb_pos_x) co.reb_pos_x[k] = x;
-                    if (co.reb_pos_z) co.reb_pos_z[k] = z;
-                } else if (co.reb_step) {
+                typedef __attribute__((address_space(1))) int32_t* g_i32p;
+                typedef __attribute__((address_space(1))) uint8_t* g_u8p;
+                typedef __attribute__((address_space(1))) double* g_f64p;
+                const g_i32p o_step = (g_i32p)co.reb_step; const g_u8p o_surface = (g_u8p)co.reb_surface;
+                const g_f64p o_velocity = (g_f64p)co.reb_velocity, o_angle = (g_f64p)co.reb_angle;
+                const g_f64p o_pos_x = (g_f64p)co.reb_pos_x, o_pos_z = (g_f64p)co.reb_pos_z;
+                const int nrm = cold->n_rebounds_max, reb_cap = cold->rebound_cap;
+                const int64_t n_rays = cold->n;
+                asm volatile("" :: "v"(o_step), "v"(o_surface), "v"(o_velocity), "v"(o_angle), "v"(o_pos_x), "v"(o_pos_z),
+                             "v"(nrm), "v"(reb_cap), "v"(n_rays));
+                if (n_reb < reb_cap) {
+                    const int64_t k = (int64_t)n_reb * n_rays + r;
+                    if (o_step) o_step[k] = i + 1;
+                    if (o_surface) o_surface[k] = hit_floor ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+                    if (o_velocity) o_velocity[k] = c;
+                    if (o_angle) o_angle[k] = ang;
+                    if (o_pos_x) o_pos_x[k] = x;
+                    if (o_pos_z) o_pos_z[k] = z;
+                } else if (o_step) {
                     status = RT2D_RAY_ERR_REBOUND_LOG;
                 }
                 n_reb += 1;
@@ -1008,7 +1021,6 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     g_pend = 10 * log10(rc);
                 }
                 if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
-                const int nrm = cold->n_rebounds_max;
                 if (nrm > -1 && n_reb > nrm) {                                  // ray.py:189-195: the point IS appended,
                     rt2d_fit(e, x, x_new, z, z_new, dx_z, x_dir);               // clipped into the bounds, and the ray ends
                     stop = RT2D_STOP_MAX_REBOUNDS;
