@@ -576,8 +576,10 @@ struct WaveLog {
 #define RT2D_FUSE2_MAX_WAVES 8     // with the rebound losses precomputed (FUSE == 2): 216 registers; at 12 waves (168, ~30 words
                                    // spilled) the step itself is faster (10.7 vs 12.0 ms per 1M rays) but the deposits twice as slow
 #endif
+#define RT2D_TAB1_MAX_WAVES 4      // launch bound of the instances with all step tables in LDS (small fans, one wave per workgroup):
+                                   // 256 vector registers instead of 128, so that the straight-line rebound does not spill
 template <bool WRITE, int TAB, int POST, bool CUTOFF, bool CEILC, int FUSE = 0>
-__global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE : FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
+__global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE : FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : TAB == 1 ? RT2D_TAB1_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
     CastCold* cold = reinterpret_cast<CastCold*>(s_mem);
@@ -943,7 +945,94 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         // (branch hints: a wave alone on its CU pays an instruction-fetch stall at every taken branch, so the common
         // step should be laid out as straight-line code)
         RT2D_WLOG(if (rt2d_any(general)) wave_log.n_gen_flag += 1ull; if (rt2d_any(steep)) wave_log.n_gen_steep += 1ull;)
-        if (__builtin_expect(rt2d_any(general), 0)) if (general) {
+        // The ordinary rebound -- pieces guessed right, the point inside the rectangle in x, a floor or (constant) surface
+        // hit that is neither the last allowed one nor beyond the log, the reflected point inside the rectangle -- in
+        // straight-line form: the same expressions in the same order as the general case below (ray.py:176-220), but every
+        // table record and the parked launch data fetched in two batches of LDS reads, every decision a select, and
+        // nothing written before all of them are made.  A lane that fails any test is left, untouched, to the general case.
+        bool reb_done = false;
+        if (TIGHT && TAB == 1 && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
+            const bool hitf = z_new < z_floor;
+            const bool hitc = !hitf & (z_new > z_ceil);
+            bool fast = general & oka & okb & (x_new >= e.range_min[0]) & (x_new <= e.range_max[0]) & (hitf | (CEILC & hitc));
+            if (fast) {
+                const double z_hit = hitf ? z_floor : z_ceil;
+                // batch 1: floor record under the previous point, sound-speed record at the surface that was hit, the slope
+                // table's description, the log's addresses and limits
+                const double xq = vmin(vmax(x, fl_lo), fl_hi);                            // rt2d_eval_lin: both tables clamp
+                const int jq = guess(e.floor, xq, fl_jmax);
+                const int jh = guess(e.cz, z_hit, cz_jmax);
+                double rq[4], rh[8];
+                load_fl(e.floor, jq, rq);
+                load_cz(e.cz, jh, rh);
+                const DevTable* st = hitf ? &cold->dx_floor : &cold->dx_ceil;
+                const double st_x0 = st->x0, st_inv_h = st->inv_h, st_lo = st->lo, st_hi = st->hi;
+                const int st_off = st->off, st_n = st->n_pieces, st_oob = st->oob, st_uniform = st->uniform;
+                const int nrm = cold->n_rebounds_max, reb_cap = cold->rebound_cap;
+                asm volatile("" :: "v"(nrm), "v"(reb_cap), "v"(st_x0), "v"(st_inv_h), "v"(st_lo), "v"(st_hi),
+                             "v"(st_off), "v"(st_n), "v"(st_oob), "v"(st_uniform), "v"(rq[1]), "v"(rq[2]), "v"(rh[1]), "v"(rh[6]));
+                fast &= ((xq >= rq[0]) | (jq == 0)) & ((xq < rq[3]) | (jq == e.floor.n_pieces - 1));          // rt2d_lookup<3>
+                fast &= ((z_hit >= rh[0]) | (jh == 0)) & ((z_hit < rh[7]) | (jh == e.cz.n_pieces - 1)) & (e.cz.uniform != 0);
+                fast &= (n_reb < reb_cap) & !((nrm > -1) & (n_reb + 1 > nrm)) & (st_uniform != 0);
+                const double fx = hitf ? rq[1] * (xq - rq[0]) + rq[2] : a.ceil_const;
+                const double xr = x + (fx - z) / dx_z;                                    // ray.py:177,200
+                // rt2d_eval_quad on the slope table of the surface that was hit
+                const double xs = (st_oob == 1) ? vmin(vmax(xr, st_lo), st_hi) : xr;
+                fast &= (st_oob != 2) | ((xr >= st_lo) & (xr <= st_hi));
+                int js;
+                {
+                    const double g = (xs - st_x0) * st_inv_h;
+                    asm("v_cvt_i32_f64 %0, %1" : "=v"(js) : "v"(g));
+                    js = min(max(js, 0), st_n - 1);
+                }
+                double rs[5];
+                {
+                    auto q = tab_slope + st_off + js * 4;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) rs[k] = q[k];
+                }
+                fast &= ((xs >= rs[0]) | (js == 0)) & ((xs < rs[4]) | (js == st_n - 1));                        // rt2d_lookup<4>
+                const double sl = rt2d_quad_of(rs, xs - rs[0], 0);
+                // reflection (ray.py:178-186, 201-209)
+                const double u0 = 1.0, u1 = sl;
+                const double n0 = hitf ? -1 * u1 : u1;
+                const double n1 = hitf ? u0 : -1 * u0;
+                const double ku = kx * u0 + kz * u1, kn = kx * n0 + kz * n1;
+                const double rx = ku * u0 - kn * n0, rzz = ku * u1 - kn * n1;
+                // all bounds (ray.py:225-230)
+                fast &= !((xr < e.range_min[0]) | (xr > e.range_max[0]) | (z_hit < e.range_min[1]) | (z_hit > e.range_max[1]));
+                if (fast) {
+                    // batch 2: the log's addresses (device memory: as the generic pointers they are parked as, the stores
+                    // would be FLAT instructions, which the next LDS read would have to wait for)
+                    const Rt2dRayOut& co = cold->out;
+                    typedef __attribute__((address_space(1))) int32_t* g_i32p;
+                    typedef __attribute__((address_space(1))) uint8_t* g_u8p;
+                    typedef __attribute__((address_space(1))) double* g_f64p;
+                    const g_i32p o_step = (g_i32p)co.reb_step; const g_u8p o_surface = (g_u8p)co.reb_surface;
+                    const g_f64p o_velocity = (g_f64p)co.reb_velocity, o_angle = (g_f64p)co.reb_angle;
+                    const g_f64p o_pos_x = (g_f64p)co.reb_pos_x, o_pos_z = (g_f64p)co.reb_pos_z;
+                    const int64_t n_rays = cold->n;
+                    asm volatile("" :: "v"(o_step), "v"(o_surface), "v"(o_velocity), "v"(o_angle), "v"(o_pos_x), "v"(o_pos_z), "v"(n_rays));
+                    const int64_t k = (int64_t)n_reb * n_rays + r;
+                    if (o_step) o_step[k] = i + 1;
+                    if (o_surface) o_surface[k] = hitf ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+                    if (o_velocity) o_velocity[k] = c;
+                    if (o_angle) {
+                        const double q = rzz / rx;
+                        o_angle[k] = 1 / sqrt(1 + q * q);                                 // ray.py:184,207 (cos of grazing angle)
+                    }
+                    if (o_pos_x) o_pos_x[k] = x;
+                    if (o_pos_z) o_pos_z[k] = z;
+                    n_reb += 1;
+                    x_new = xr; z_new = z_hit;
+                    kx = rx; kz = rzz;
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) rz[k8] = rh[k8];
+                    reb_done = true;
+                }
+            }
+        }
+        if (__builtin_expect(rt2d_any(general & !reb_done), 0)) if (general & !reb_done) {
             if (want_margin) margin = fmin(margin, rt2d_bound_margin(e, x_new, z_new));
             // horizontal bounds first (ray.py:162-167): stop only if fit_to_bounds ends on code 1 or 2, i.e. the point
             // clipped in x is still inside in z; the clipped point is NOT appended
@@ -2470,6 +2559,7 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
         while (wpb < 16 && (waves + wpb - 1) / wpb > n_cu * per_cu) wpb *= 2;
         if (hybrid) wpb = 2;
         if (const char* w = getenv("RT2D_CAST_WPB")) { const int v = atoi(w); if (v >= 1 && v <= 16) wpb = v; }
+        if (!hybrid && in_lds && wpb > RT2D_TAB1_MAX_WAVES) wpb = RT2D_TAB1_MAX_WAVES;     // that instance's launch bound
         block = wpb * RT2D_WAVE;
     }
     const int64_t rays_per_block = (int64_t)(block / RT2D_WAVE) * a.lanes;

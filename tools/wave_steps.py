@@ -25,7 +25,7 @@ source = np.array([0., 0.])
 fan = rt.RayFan(env, source, angles, **bench.PROP)
 torch.cuda.synchronize()
 cap = 1 << 16
-log = torch.zeros((cap, 24), dtype=torch.int64, device='cuda')
+log = torch.zeros((cap, 12), dtype=torch.int64, device='cuda')
 L.rt2d_debug_wave_log(log.data_ptr(), cap)
 fan = rt.RayFan(env, source, angles, **bench.PROP)
 torch.cuda.synchronize()
@@ -43,5 +43,3 @@ nt, ng, tt, tg = lg[:, 4].sum(), lg[:, 5].sum(), lg[:, 6].sum() / 100., lg[:, 7]
 print(f'tight loop, shader clocks per step: head (update, guesses, LDS, decision) {lg[:, 8].sum() / max(nt, 1):.0f}, tail (commit, division) {lg[:, 9].sum() / max(nt, 1):.0f}')
 print(f'all waves: {nt} tight steps in {tt:.0f} wave-us ({1e3 * tt / nt:.0f} ns each), {ng} general iterations in {tg:.0f} wave-us ({1e3 * tg / ng:.0f} ns each)')
 
-ph = lg[:, 12:20].sum(0)
-print('rebound phases (clocks per rebound of lane 0):', [round(float(v) / max(ph[7], 1)) for v in ph[:7]], 'rebounds', int(ph[7]))
