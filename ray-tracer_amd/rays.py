@@ -37,6 +37,8 @@ CHUNK_RAYS = int(os.environ.get('RT2D_CHUNK_RAYS', 0))               # rays cast
 CHUNKED_MIN_RAYS = int(os.environ.get('RT2D_CHUNKED_MIN_RAYS', 1 << 18))   # store=False fans from here on use it (smaller: fused kernel)
 ONEPASS_MIN_ROWS, ONEPASS_ROWS_DIV = 4096, 8      # rows of the compact gain array of a one-pass map queued without waiting: max(.., n / ..)
 CHUNK_STREAMS = int(os.environ.get('RT2D_CHUNK_STREAMS', 2))
+MULTI_GROUP = int(os.environ.get('RT2D_MULTI_GROUP', 16))         # frequencies per group of heatmap_accumulate_multi's pipeline (0: off)
+MULTI_PIPELINE_MIN = 1 << 20                                      # rays x frequencies from which it is used
 SIDE_STREAM = os.environ.get('RT2D_SIDE_STREAM', '1') != '0'      # side fans of the fused heat map on a second stream
 SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat map hands rays to the stored path
 LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
@@ -892,18 +894,43 @@ class RayFan:
         torch = _torch()
         L = _lib.lib()
         freqs = list(freqs)
-        self.populate(*freqs)
         with torch.cuda.device(self.device):
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
             work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device)
             if self.n > HEATMAP_FAST_MIN_RAYS:
                 ray_mask = self.heatmap_mask(res, shape, ray_mask)
-            ptrs = torch.tensor([self.G[f].data_ptr() for f in freqs], dtype=torch.int64, device=self.device)
-            _lib.check(L.rt2d_heatmap_accumulate_multi(self.X.data_ptr(), self.Z.data_ptr(), ptrs.data_ptr(), len(freqs),
-                                                       self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, _ptr(ray_mask),
-                                                       res_c, shape_c, H.data_ptr(), _ptr(dropped), work.data_ptr(),
-                                                       _raw_stream()))
+
+            def bin_maps(k0, k1):
+                ptrs = torch.tensor([self.G[f].data_ptr() for f in freqs[k0:k1]], dtype=torch.int64, device=self.device)
+                _lib.check(L.rt2d_heatmap_accumulate_multi(self.X.data_ptr(), self.Z.data_ptr(), ptrs.data_ptr(), k1 - k0,
+                                                           self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, _ptr(ray_mask),
+                                                           res_c, shape_c, H[k0:k1].data_ptr(), _ptr(dropped), work.data_ptr(),
+                                                           _raw_stream()))
+
+            # Binning is bound by the f64 atomics of the L2s, the gain by vector issue and HBM: with many new frequencies on
+            # a big fan the gain of the next group of frequencies runs on a second stream beside the binning of this one.
+            group = MULTI_GROUP
+            missing = [f for f in freqs if f not in self.G]
+            if group > 0 and len(missing) > group and self.n * len(freqs) >= MULTI_PIPELINE_MIN:
+                main, side = torch.cuda.current_stream(), _side_stream(self.device, 0)
+                side.wait_stream(main)                               # the trajectories are ready where main stands now
+                bounds = list(range(0, len(freqs), group)) + [len(freqs)]
+                self.populate(*freqs[bounds[0]:bounds[1]])
+                for g in range(len(bounds) - 1):
+                    ready = None
+                    if g + 2 < len(bounds):
+                        with torch.cuda.stream(side):
+                            self.populate(*freqs[bounds[g + 1]:bounds[g + 2]])
+                            ready = side.record_event()
+                        for f in freqs[bounds[g + 1]:bounds[g + 2]]:
+                            self.G[f].record_stream(main)
+                    bin_maps(bounds[g], bounds[g + 1])
+                    if ready is not None:
+                        main.wait_event(ready)
+            else:
+                self.populate(*freqs)
+                bin_maps(0, len(freqs))
             self._last_slow = work
 
     @property

@@ -300,6 +300,31 @@ def test_heatmaps_for_an_array_of_frequencies(rt, orc):
 
 
 @pytest.mark.gpu
+def test_heatmaps_with_the_gain_of_the_next_frequencies_beside_the_binning(rt, monkeypatch):
+    """Many new frequencies on a big fan: the gain of the next group runs on a second stream beside the binning of this
+    one (RayFan.heatmap_accumulate_multi).  Same maps as with everything on one stream, to the order of the atomics."""
+    from ray_tracer_amd import rays as rays_mod
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    n, F = 16384, 12
+    angles = -(np.arange(n) + 1) * (0.999 / n)
+    freqs = [float(f) for f in np.geomspace(20., 15000., F)]
+    maps = {}
+    for group in (4, 0):
+        monkeypatch.setattr(rays_mod, 'MULTI_GROUP', group)
+        monkeypatch.setattr(rays_mod, 'MULTI_PIPELINE_MIN', 1)
+        sim = rt.Simulation2D(env, g['fan_source'])
+        fan = sim.cast(angles, **common.prop_kwargs(g))
+        maps[group] = sim.heatmaps(freqs, resolution=[50, 25], cutoff=.1)
+        assert set(fan.G) >= set(freqs)
+    for f in freqs:
+        fin = np.isfinite(maps[0][f])
+        assert np.array_equal(np.isfinite(maps[4][f]), fin)
+        assert np.abs(maps[4][f] - maps[0][f])[fin].max(initial=0) < 1e-12
+    assert np.nanmax(np.abs(maps[4][freqs[0]] - maps[4][freqs[-1]])) > 1e-3
+
+
+@pytest.mark.gpu
 def test_extreme_gains_take_the_pow_path_in_both_kernels(rt):
     """Gains beyond +-3000 dB (a rebound coefficient that underflowed to 0 gives -inf) leave the 2^x shortcut for the
     reference's two pows (ray.py:317, simulation.py:129): (10^(G/10))^-0.1 is inf / 0 there.  The tile kernel keeps
