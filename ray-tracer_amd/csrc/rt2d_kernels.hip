@@ -338,6 +338,7 @@ struct CastArgs {
     double inv_dx_max;            // RN(1 / dx_max), for rt2d_div_by_const
     double ceil_const;            // the surface depth when the surface table is constant (CEILC kernels)
     int32_t lanes;                // rays per wave (1..64, power of two): small fans are spread over more waves
+    int32_t tight_off;            // experiments (RT2D_CAST_TIGHT=0): 1 = general loop only; 2 = no tight loop with the whole post-pass
     unsigned long long* wave_log; // development aid (rt2d_debug_wave_log): per wave [start, end] of the 100 MHz clock and its hardware id
     int64_t wave_log_cap;
     // fused cast -> gain -> heat map (FUSE kernels)
@@ -765,8 +766,9 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // points, the choice of the division) is carried through it.  The step that the wave cannot take together is left
     // untouched for the general loop, which then tries the tight loop again.  (The waves of a small fan hold four shallow
     // rays that rebound twenty times in 1500 steps: they spend nine steps in ten here.)
-    constexpr bool TIGHT = (POST <= 1) && !CUTOFF && (FUSE == 0);
-    bool tight_on = TIGHT && !(WRITE && a.C != nullptr);
+    constexpr bool TIGHT = !CUTOFF && (FUSE == 0) && (POST <= 1 || TAB == 1);     // (with the whole post-pass only where 256
+                                                                                    // registers are to be had: it needs 175)
+    bool tight_on = TIGHT && !(WRITE && a.C != nullptr) && !want_margin && a.tight_off != 1 && !(FULL && a.tight_off == 2);      // (the decision margin is a test output: general loop)
     // Wave-uniform facts the tight loop leans on, established once:
     //  - every guessed piece is verified against its two breaks, which needs the uniform-grid hint of all three tables;
     //  - the guesses are clamped to the pieces that lie WHOLLY inside the rectangle (floor pieces in x, sound-speed
@@ -869,10 +871,19 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     RT2D_WLOG(const unsigned long long c_b = __builtin_amdgcn_s_memtime();)
                     // commit (ray.py:235-247)
                     if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
+                    if (FULL) {                                                       // ray.py:271-275
+                        const double ddx = xn - x, ddz = zn - z;
+                        const double dL = sqrt(ddx * ddx + ddz * ddz);
+                        L += dL; T += dL / c_pt;
+                    }
                     x = xn; z = zn;
                     const double dzr_t = z - tz8[0];
                     c = rt2d_quad_of(tz8, dzr_t, 0);
                     const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
+                    if (FULL) {
+                        c_pt = c;
+                        if (has_target) tt.add(x, z, T, n_pts + (i - i_in), tx);
+                    }
                     if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
                     if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
                     if (ST) {
@@ -951,7 +962,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         // table record and the parked launch data fetched in two batches of LDS reads, every decision a select, and
         // nothing written before all of them are made.  A lane that fails any test is left, untouched, to the general case.
         bool reb_done = false;
-        if (TIGHT && TAB == 1 && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
+        if (TIGHT && TAB == 1 && !want_margin && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
             const bool hitf = z_new < z_floor;
             const bool hitc = !hitf & (z_new > z_ceil);
             bool fast = general & oka & okb & (x_new >= e.range_min[0]) & (x_new <= e.range_max[0]) & (hitf | (CEILC & hitc));
@@ -969,11 +980,14 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 const double st_x0 = st->x0, st_inv_h = st->inv_h, st_lo = st->lo, st_hi = st->hi;
                 const int st_off = st->off, st_n = st->n_pieces, st_oob = st->oob, st_uniform = st->uniform;
                 const int nrm = cold->n_rebounds_max, reb_cap = cold->rebound_cap;
-                asm volatile("" :: "v"(nrm), "v"(reb_cap), "v"(st_x0), "v"(st_inv_h), "v"(st_lo), "v"(st_hi),
+                const bool has_log = cold->out.reb_step != nullptr;
+                asm volatile("" :: "v"(nrm), "v"(reb_cap), "v"(has_log), "v"(st_x0), "v"(st_inv_h), "v"(st_lo), "v"(st_hi),
                              "v"(st_off), "v"(st_n), "v"(st_oob), "v"(st_uniform), "v"(rq[1]), "v"(rq[2]), "v"(rh[1]), "v"(rh[6]));
                 fast &= ((xq >= rq[0]) | (jq == 0)) & ((xq < rq[3]) | (jq == e.floor.n_pieces - 1));          // rt2d_lookup<3>
                 fast &= ((z_hit >= rh[0]) | (jh == 0)) & ((z_hit < rh[7]) | (jh == e.cz.n_pieces - 1)) & (e.cz.uniform != 0);
-                fast &= (n_reb < reb_cap) & !((nrm > -1) & (n_reb + 1 > nrm)) & (st_uniform != 0);
+                // (a rebound beyond the log's room is an error only when there is a log: a cast without one just goes on)
+                const bool log_it = n_reb < reb_cap;
+                fast &= (log_it | !has_log) & !((nrm > -1) & (n_reb + 1 > nrm)) & (st_uniform != 0);
                 const double fx = hitf ? rq[1] * (xq - rq[0]) + rq[2] : a.ceil_const;
                 const double xr = x + (fx - z) / dx_z;                                    // ray.py:177,200
                 // rt2d_eval_quad on the slope table of the surface that was hit
@@ -1013,16 +1027,18 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     const g_f64p o_pos_x = (g_f64p)co.reb_pos_x, o_pos_z = (g_f64p)co.reb_pos_z;
                     const int64_t n_rays = cold->n;
                     asm volatile("" :: "v"(o_step), "v"(o_surface), "v"(o_velocity), "v"(o_angle), "v"(o_pos_x), "v"(o_pos_z), "v"(n_rays));
-                    const int64_t k = (int64_t)n_reb * n_rays + r;
-                    if (o_step) o_step[k] = i + 1;
-                    if (o_surface) o_surface[k] = hitf ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
-                    if (o_velocity) o_velocity[k] = c;
-                    if (o_angle) {
-                        const double q = rzz / rx;
-                        o_angle[k] = 1 / sqrt(1 + q * q);                                 // ray.py:184,207 (cos of grazing angle)
+                    if (log_it) {
+                        const int64_t k = (int64_t)n_reb * n_rays + r;
+                        if (o_step) o_step[k] = i + 1;
+                        if (o_surface) o_surface[k] = hitf ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+                        if (o_velocity) o_velocity[k] = c;
+                        if (o_angle) {
+                            const double q = rzz / rx;
+                            o_angle[k] = 1 / sqrt(1 + q * q);                             // ray.py:184,207 (cos of grazing angle)
+                        }
+                        if (o_pos_x) o_pos_x[k] = x;
+                        if (o_pos_z) o_pos_z[k] = z;
                     }
-                    if (o_pos_x) o_pos_x[k] = x;
-                    if (o_pos_z) o_pos_z[k] = z;
                     n_reb += 1;
                     x_new = xr; z_new = z_hit;
                     kx = rx; kz = rzz;
@@ -2540,6 +2556,7 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     // (1024 threads share one LDS copy of the tables).
     int block = RT2D_WAVE;
     a.lanes = RT2D_WAVE;
+    { static const int t_env = getenv("RT2D_CAST_TIGHT") ? atoi(getenv("RT2D_CAST_TIGHT")) : -1; a.tight_off = t_env == 0 ? 1 : t_env == 1 ? 2 : 0; }
     if (n <= n_cu * RT2D_WAVE) {
         int lanes = 1;
         while ((int64_t)lanes * n_cu < n) lanes *= 2;
