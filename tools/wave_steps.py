@@ -21,13 +21,20 @@ L = _lib.lib()
 L.rt2d_debug_wave_log.argtypes = [C.c_void_p, C.c_int64]
 L.rt2d_debug_wave_log.restype = None
 angles = -(np.arange(n) + 1) * (0.999 / n) if n != 999 else -(np.arange(999) + 1) / 1000.
+prop = dict(bench.PROP)
+kw = {}
+if len(sys.argv) > 3:      # python tools/wave_steps.py N lo hi [n_steps_max n_rebounds_max]: a cone of steep rays as the refine loop casts
+    angles = -np.linspace(float(sys.argv[2]), float(sys.argv[3]), n)
+    if len(sys.argv) > 5:
+        prop.update(n_steps_max=int(sys.argv[4]), n_rebounds_max=int(sys.argv[5]))
+    kw = dict(target=np.array([30000., -300.]), store=False)
 source = np.array([0., 0.])
-fan = rt.RayFan(env, source, angles, **bench.PROP)
+fan = rt.RayFan(env, source, angles, **prop, **kw)
 torch.cuda.synchronize()
 cap = 1 << 16
 log = torch.zeros((cap, 12), dtype=torch.int64, device='cuda')
 L.rt2d_debug_wave_log(log.data_ptr(), cap)
-fan = rt.RayFan(env, source, angles, **bench.PROP)
+fan = rt.RayFan(env, source, angles, **prop, **kw)
 torch.cuda.synchronize()
 L.rt2d_debug_wave_log(None, 0)
 lg = log.cpu().numpy()
