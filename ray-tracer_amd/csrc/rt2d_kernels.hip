@@ -800,6 +800,93 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         tight_on = tight_on && rt2d_all(room == room_u);
         tight_end = min(tight_end, room_u - 1);
     }
+    // The ordinary rebound (ray.py:176-220) in straight-line form: pieces guessed right, a floor or (constant) surface hit that
+    // is neither the last allowed one nor beyond the log, the reflected point inside the rectangle -- the same expressions
+    // in the same order as the general case of the general step, but every table record and the parked launch data
+    // fetched in two batches of LDS reads, every decision a select, and nothing written before all of them are made.
+    // rebound_examine works on the step from (x, z) with the scaled direction (kxs, kzs) and the surfaces (z_fl, z_ce) under
+    // the point that was hit; it returns false for anything unusual (the caller then leaves the ray to the general case).
+    struct RebOut { double xr, z_hit, rx, rzz, rh[8]; bool log_it; };
+    auto rebound_examine = [&](bool hitf, double z_fl, double z_ce, double kxs, double kzs, RebOut& o) -> bool {
+        bool fast = true;
+        const double z_hit = hitf ? z_fl : z_ce;
+        // batch 1: floor record under the previous point, sound-speed record at the surface that was hit, the slope
+        // table's description, the limits
+        const double xq = vmin(vmax(x, fl_lo), fl_hi);                                    // rt2d_eval_lin: both tables clamp
+        const int jq = guess(e.floor, xq, fl_jmax);
+        const int jh = guess(e.cz, z_hit, cz_jmax);
+        double rq[4];
+        load_fl(e.floor, jq, rq);
+        load_cz(e.cz, jh, o.rh);
+        const DevTable* st = hitf ? &cold->dx_floor : &cold->dx_ceil;
+        const double st_x0 = st->x0, st_inv_h = st->inv_h, st_lo = st->lo, st_hi = st->hi;
+        const int st_off = st->off, st_n = st->n_pieces, st_oob = st->oob, st_uniform = st->uniform;
+        const int nrm = cold->n_rebounds_max, reb_cap = cold->rebound_cap;
+        const bool has_log = cold->out.reb_step != nullptr;
+        asm volatile("" :: "v"(nrm), "v"(reb_cap), "v"(has_log), "v"(st_x0), "v"(st_inv_h), "v"(st_lo), "v"(st_hi),
+                     "v"(st_off), "v"(st_n), "v"(st_oob), "v"(st_uniform), "v"(rq[1]), "v"(rq[2]), "v"(o.rh[1]), "v"(o.rh[6]));
+        fast &= ((xq >= rq[0]) | (jq == 0)) & ((xq < rq[3]) | (jq == e.floor.n_pieces - 1));                  // rt2d_lookup<3>
+        fast &= ((z_hit >= o.rh[0]) | (jh == 0)) & ((z_hit < o.rh[7]) | (jh == e.cz.n_pieces - 1)) & (e.cz.uniform != 0);
+        // (a rebound beyond the log's room is an error only when there is a log: a cast without one just goes on)
+        o.log_it = n_reb < reb_cap;
+        fast &= (o.log_it | !has_log) & !((nrm > -1) & (n_reb + 1 > nrm)) & (st_uniform != 0);
+        const double fx = hitf ? rq[1] * (xq - rq[0]) + rq[2] : a.ceil_const;
+        const double xr = x + (fx - z) / dx_z;                                            // ray.py:177,200
+        // rt2d_eval_quad on the slope table of the surface that was hit
+        const double xs = (st_oob == 1) ? vmin(vmax(xr, st_lo), st_hi) : xr;
+        fast &= (st_oob != 2) | ((xr >= st_lo) & (xr <= st_hi));
+        int js;
+        {
+            const double g = (xs - st_x0) * st_inv_h;
+            asm("v_cvt_i32_f64 %0, %1" : "=v"(js) : "v"(g));
+            js = min(max(js, 0), st_n - 1);
+        }
+        double rs[5];
+        {
+            auto q = tab_slope + st_off + js * 4;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rs[k] = q[k];
+        }
+        fast &= ((xs >= rs[0]) | (js == 0)) & ((xs < rs[4]) | (js == st_n - 1));                                // rt2d_lookup<4>
+        const double sl = rt2d_quad_of(rs, xs - rs[0], 0);
+        // reflection (ray.py:178-186, 201-209)
+        const double u0 = 1.0, u1 = sl;
+        const double n0 = hitf ? -1 * u1 : u1;
+        const double n1 = hitf ? u0 : -1 * u0;
+        const double ku = kxs * u0 + kzs * u1, kn = kxs * n0 + kzs * n1;
+        o.rx = ku * u0 - kn * n0; o.rzz = ku * u1 - kn * n1;
+        o.xr = xr; o.z_hit = z_hit;
+        // all bounds (ray.py:225-230)
+        fast &= !((xr < e.range_min[0]) | (xr > e.range_max[0]) | (z_hit < e.range_min[1]) | (z_hit > e.range_max[1]));
+        return fast;
+    };
+    // ... and its entry in the rebound log (x, z, c: still the point before the rebound; step: i + 1, ray.py:211-218)
+    auto rebound_log = [&](bool hitf, const RebOut& o, int step_no) {
+        // batch 2: the log's addresses (device memory: as the generic pointers they are parked as, the stores would be
+        // FLAT instructions, which the next LDS read would have to wait for)
+        const Rt2dRayOut& co = cold->out;
+        typedef __attribute__((address_space(1))) int32_t* g_i32p;
+        typedef __attribute__((address_space(1))) uint8_t* g_u8p;
+        typedef __attribute__((address_space(1))) double* g_f64p;
+        const g_i32p o_step = (g_i32p)co.reb_step; const g_u8p o_surface = (g_u8p)co.reb_surface;
+        const g_f64p o_velocity = (g_f64p)co.reb_velocity, o_angle = (g_f64p)co.reb_angle;
+        const g_f64p o_pos_x = (g_f64p)co.reb_pos_x, o_pos_z = (g_f64p)co.reb_pos_z;
+        const int64_t n_rays = cold->n;
+        asm volatile("" :: "v"(o_step), "v"(o_surface), "v"(o_velocity), "v"(o_angle), "v"(o_pos_x), "v"(o_pos_z), "v"(n_rays));
+        if (o.log_it) {
+            const int64_t k = (int64_t)n_reb * n_rays + r;
+            if (o_step) o_step[k] = step_no;
+            if (o_surface) o_surface[k] = hitf ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
+            if (o_velocity) o_velocity[k] = c;
+            if (o_angle) {
+                const double q = o.rzz / o.rx;
+                o_angle[k] = 1 / sqrt(1 + q * q);                                         // ray.py:184,207 (cos of grazing angle)
+            }
+            if (o_pos_x) o_pos_x[k] = x;
+            if (o_pos_z) o_pos_z[k] = z;
+        }
+        n_reb += 1;
+    };
     double dx_z_max_v = dx_z_max;
     int fl_j1_v = fl_j1, cz_j1_v = cz_j1, ce_j1_v = ce_jmax;
     asm volatile("" : "+v"(dx_z_max_v), "+v"(fl_j1_v), "+v"(cz_j1_v));
@@ -826,10 +913,10 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 const unsigned int flip = (kx_p < 0.0) ? 0x80000000u : 0u;       // k1/k0 changes sign with k0
                 // The loop is written rotated -- examine a step, then { commit it; examine the next } while it can be taken
                 // -- so that an iteration ends in its one conditional branch.
-                double kx_s = kx_p, kz_s, xn, zn, tz8[8];
+                double kx_s = kx_p, kz_s, xn, zn, ta[4], tb[4], tz8[8], zf_t, zc_t = 0.0;
+                unsigned long long steep_t = 0ull;
                 auto examine = [&]() -> bool {
                     RT2D_WLOG(const unsigned long long c_a = __builtin_amdgcn_s_memtime();)
-                    unsigned long long steep_t = 0ull;
                     if (ST) {
                         const double ss = p.dz_max / fabs(dx_z);                   // ray.py:153
                         const bool st = fabs(dx_z) > dx_z_max;
@@ -843,7 +930,6 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     // (no clamp of xn into the tables: a point outside them is in no piece and fails below)
                     const int ja_t = guess_in(e.floor, xn, fl_j0, fl_j1_v), jb_t = CEILC ? 0 : guess_in(e.ceil, xn, 0, ce_j1_v);
                     const int jz_t = guess_in(e.cz, zn, cz_j0, cz_j1_v);
-                    double ta[4], tb[4];
                     load_fl(e.floor, ja_t, ta);
                     if (!CEILC) load_fl(e.ceil, jb_t, tb);
                     load_cz(e.cz, jz_t, tz8);
@@ -852,13 +938,13 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     asm volatile("" :: "v"(ta[1]), "v"(ta[2]), "v"(tz8[1]), "v"(tz8[2]), "v"(tz8[3]), "v"(tz8[4]), "v"(tz8[5]), "v"(tz8[6]));
                     // the guessed pieces must be the right ones WITHOUT the end-piece exceptions of the general step (a point
                     // in an end piece that fails here is simply left to the general step)
-                    const double zf_t = ta[1] * (xn - ta[0]) + ta[2];
+                    zf_t = ta[1] * (xn - ta[0]) + ta[2];
                     unsigned long long ok_t = m_ge(xn, ta[0]) & m_lt(xn, ta[3]) & m_ge(zn, tz8[0]) & m_lt(zn, tz8[7]) & m_ge(zn, zf_t);
                     if (!ST) ok_t &= m_abs_ngt(dx_z, dx_z_max_v) & m_abs_ge(kz_s, 1e-250);
                     if (CEILC) {
                         ok_t &= m_le(zn, z_hi_bound);
                     } else {
-                        const double zc_t = tb[1] * (xn - tb[0]) + tb[2];
+                        zc_t = tb[1] * (xn - tb[0]) + tb[2];
                         ok_t &= m_ge(xn, tb[0]) & m_lt(xn, tb[3]) & m_le(zn, vmin(z_hi_bound, zc_t));
                     }
                     RT2D_WLOG(wave_log.clk_head += __builtin_amdgcn_s_memtime() - c_a;)
@@ -866,37 +952,97 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     const unsigned long long go_t = ((i < tight_end) & (!ST | (steep_t != 0ull))) ? ok_t : 0ull;
                     return (lanes_on & ~go_t) == 0ull;
                 };
-                if (examine())
-                do {
-                    RT2D_WLOG(const unsigned long long c_b = __builtin_amdgcn_s_memtime();)
-                    // commit (ray.py:235-247)
+                // A step that cannot be taken as it stands because some rays REBOUND in it -- ordinarily (rebound_examine),
+                // without turning back in x -- while every other ray's step is plain is taken here as well (small-fan
+                // instances): the exit into the general loop and back costs more than the rebound itself.  The expressions are
+                // those of the general step for such a wave (the IEEE k1/k0 for every ray, as there when one ray rebounds).
+                auto mixed_step = [&]() -> bool {
+                    if (TAB != 1 || !(i < tight_end) || (ST && steep_t == 0ull)) return false;
+                    const bool in_x = (xn >= ta[0]) & (xn < ta[3]) & (CEILC | ((xn >= tb[0]) & (xn < tb[3])));
+                    const bool form = ST | (!(fabs(dx_z) > dx_z_max) & (fabs(kz_s) >= 1e-250));
+                    const double z_ce = CEILC ? a.ceil_const : zc_t;
+                    const bool hitf = zn < zf_t;
+                    const bool hitc = !hitf & (zn > z_ce);
+                    const bool plain_l = in_x & form & (zn >= tz8[0]) & (zn < tz8[7]) & !hitf
+                                       & (zn <= (CEILC ? z_hi_bound : vmin(z_hi_bound, zc_t)));
+                    const bool cand = in_x & form & (hitf | (CEILC & hitc));
+                    if (!rt2d_all(plain_l | cand)) return false;
+                    RebOut o;
+                    bool fast = false;
+                    if (cand) {
+                        fast = rebound_examine(hitf, zf_t, z_ce, kx_s, kz_s, o);
+                        fast &= (kx > 0.0) ? (o.rx > 0.0) : (o.rx < 0.0);                // x_dir (ray.py:242) stays what it is
+                    }
+                    if (rt2d_any(cand & !fast)) return false;
+                    // commit (ray.py:211-218, 235-247)
                     if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
-                    if (FULL) {                                                       // ray.py:271-275
-                        const double ddx = xn - x, ddz = zn - z;
+                    const double xa_t = cand ? o.xr : xn, za_t = cand ? o.z_hit : zn;
+                    if (FULL) {
+                        const double ddx = xa_t - x, ddz = za_t - z;
                         const double dL = sqrt(ddx * ddx + ddz * ddz);
                         L += dL; T += dL / c_pt;
                     }
-                    x = xn; z = zn;
-                    const double dzr_t = z - tz8[0];
-                    c = rt2d_quad_of(tz8, dzr_t, 0);
-                    const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
+                    if (cand) rebound_log(hitf, o, i + 1);
+                    if (POST >= 1) mono &= !(xa_t < x);
+                    x = xa_t; z = za_t;
+                    double rec[8];
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) rec[k8] = cand ? o.rh[k8] : tz8[k8];
+                    const double dzr_t = z - rec[0];
+                    c = rt2d_quad_of(rec, dzr_t, 0);
+                    const double dz_c_t = rt2d_quad_of(rec, dzr_t, 1);
                     if (FULL) {
                         c_pt = c;
                         if (has_target) tt.add(x, z, T, n_pts + (i - i_in), tx);
                     }
-                    if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
-                    if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
-                    if (ST) {
-                        dx_z = kz_s / kx_s;                                               // k1/k0 (ray.py:243)
-                    } else {
-                        const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);
-                        dx_z = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_t) ^ ((unsigned long long)flip << 32)));
+                    if (POST >= 1) {
+                        min_x = vmin(min_x, x); max_x = vmax(max_x, x);
+                        min_z = vmin(min_z, z); max_z = vmax(max_z, z);
                     }
+                    if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
+                    const double k0 = cand ? o.rx : kx_s, k1 = cand ? o.rzz : kz_s;
+                    dx_z = k1 / k0;                                                       // ray.py:243
                     const double dxdx_t = mult * dz_c_t / (c * c * c);
-                    dx_z += dxdx_t * kx_s;
+                    dx_z += dxdx_t * k0;
                     ++i;
-                    RT2D_WLOG(asm volatile("" :: "v"(dx_z)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
-                } while (examine());
+                    return true;
+                };
+                bool go = examine();
+                for (;;) {
+                    while (go) {
+                        RT2D_WLOG(const unsigned long long c_b = __builtin_amdgcn_s_memtime();)
+                        // commit (ray.py:235-247)
+                        if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
+                        if (FULL) {                                                       // ray.py:271-275
+                            const double ddx = xn - x, ddz = zn - z;
+                            const double dL = sqrt(ddx * ddx + ddz * ddz);
+                            L += dL; T += dL / c_pt;
+                        }
+                        x = xn; z = zn;
+                        const double dzr_t = z - tz8[0];
+                        c = rt2d_quad_of(tz8, dzr_t, 0);
+                        const double dz_c_t = rt2d_quad_of(tz8, dzr_t, 1);
+                        if (FULL) {
+                            c_pt = c;
+                            if (has_target) tt.add(x, z, T, n_pts + (i - i_in), tx);
+                        }
+                        if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
+                        if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
+                        if (ST) {
+                            dx_z = kz_s / kx_s;                                               // k1/k0 (ray.py:243)
+                        } else {
+                            const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);
+                            dx_z = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_t) ^ ((unsigned long long)flip << 32)));
+                        }
+                        const double dxdx_t = mult * dz_c_t / (c * c * c);
+                        dx_z += dxdx_t * kx_s;
+                        ++i;
+                        RT2D_WLOG(asm volatile("" :: "v"(dx_z)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
+                        go = examine();
+                    }
+                    if (!mixed_step()) break;
+                    go = examine();
+                }
             };
             if (rt2d_all(fabs(kx) == 1.0)) {
                 stretch(std::false_type{});
@@ -956,94 +1102,21 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         // (branch hints: a wave alone on its CU pays an instruction-fetch stall at every taken branch, so the common
         // step should be laid out as straight-line code)
         RT2D_WLOG(if (rt2d_any(general)) wave_log.n_gen_flag += 1ull; if (rt2d_any(steep)) wave_log.n_gen_steep += 1ull;)
-        // The ordinary rebound -- pieces guessed right, the point inside the rectangle in x, a floor or (constant) surface
-        // hit that is neither the last allowed one nor beyond the log, the reflected point inside the rectangle -- in
-        // straight-line form: the same expressions in the same order as the general case below (ray.py:176-220), but every
-        // table record and the parked launch data fetched in two batches of LDS reads, every decision a select, and
-        // nothing written before all of them are made.  A lane that fails any test is left, untouched, to the general case.
+        // The ordinary rebound in its straight-line form (rebound_examine above); a lane that fails any test is left,
+        // untouched, to the general case.
         bool reb_done = false;
         if (TIGHT && TAB == 1 && !want_margin && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
             const bool hitf = z_new < z_floor;
             const bool hitc = !hitf & (z_new > z_ceil);
-            bool fast = general & oka & okb & (x_new >= e.range_min[0]) & (x_new <= e.range_max[0]) & (hitf | (CEILC & hitc));
-            if (fast) {
-                const double z_hit = hitf ? z_floor : z_ceil;
-                // batch 1: floor record under the previous point, sound-speed record at the surface that was hit, the slope
-                // table's description, the log's addresses and limits
-                const double xq = vmin(vmax(x, fl_lo), fl_hi);                            // rt2d_eval_lin: both tables clamp
-                const int jq = guess(e.floor, xq, fl_jmax);
-                const int jh = guess(e.cz, z_hit, cz_jmax);
-                double rq[4], rh[8];
-                load_fl(e.floor, jq, rq);
-                load_cz(e.cz, jh, rh);
-                const DevTable* st = hitf ? &cold->dx_floor : &cold->dx_ceil;
-                const double st_x0 = st->x0, st_inv_h = st->inv_h, st_lo = st->lo, st_hi = st->hi;
-                const int st_off = st->off, st_n = st->n_pieces, st_oob = st->oob, st_uniform = st->uniform;
-                const int nrm = cold->n_rebounds_max, reb_cap = cold->rebound_cap;
-                const bool has_log = cold->out.reb_step != nullptr;
-                asm volatile("" :: "v"(nrm), "v"(reb_cap), "v"(has_log), "v"(st_x0), "v"(st_inv_h), "v"(st_lo), "v"(st_hi),
-                             "v"(st_off), "v"(st_n), "v"(st_oob), "v"(st_uniform), "v"(rq[1]), "v"(rq[2]), "v"(rh[1]), "v"(rh[6]));
-                fast &= ((xq >= rq[0]) | (jq == 0)) & ((xq < rq[3]) | (jq == e.floor.n_pieces - 1));          // rt2d_lookup<3>
-                fast &= ((z_hit >= rh[0]) | (jh == 0)) & ((z_hit < rh[7]) | (jh == e.cz.n_pieces - 1)) & (e.cz.uniform != 0);
-                // (a rebound beyond the log's room is an error only when there is a log: a cast without one just goes on)
-                const bool log_it = n_reb < reb_cap;
-                fast &= (log_it | !has_log) & !((nrm > -1) & (n_reb + 1 > nrm)) & (st_uniform != 0);
-                const double fx = hitf ? rq[1] * (xq - rq[0]) + rq[2] : a.ceil_const;
-                const double xr = x + (fx - z) / dx_z;                                    // ray.py:177,200
-                // rt2d_eval_quad on the slope table of the surface that was hit
-                const double xs = (st_oob == 1) ? vmin(vmax(xr, st_lo), st_hi) : xr;
-                fast &= (st_oob != 2) | ((xr >= st_lo) & (xr <= st_hi));
-                int js;
-                {
-                    const double g = (xs - st_x0) * st_inv_h;
-                    asm("v_cvt_i32_f64 %0, %1" : "=v"(js) : "v"(g));
-                    js = min(max(js, 0), st_n - 1);
-                }
-                double rs[5];
-                {
-                    auto q = tab_slope + st_off + js * 4;
+            const bool cand = general & oka & okb & (x_new >= e.range_min[0]) & (x_new <= e.range_max[0]) & (hitf | (CEILC & hitc));
+            if (cand) {
+                RebOut o;
+                if (rebound_examine(hitf, z_floor, z_ceil, kx, kz, o)) {
+                    rebound_log(hitf, o, i + 1);
+                    x_new = o.xr; z_new = o.z_hit;
+                    kx = o.rx; kz = o.rzz;
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) rs[k] = q[k];
-                }
-                fast &= ((xs >= rs[0]) | (js == 0)) & ((xs < rs[4]) | (js == st_n - 1));                        // rt2d_lookup<4>
-                const double sl = rt2d_quad_of(rs, xs - rs[0], 0);
-                // reflection (ray.py:178-186, 201-209)
-                const double u0 = 1.0, u1 = sl;
-                const double n0 = hitf ? -1 * u1 : u1;
-                const double n1 = hitf ? u0 : -1 * u0;
-                const double ku = kx * u0 + kz * u1, kn = kx * n0 + kz * n1;
-                const double rx = ku * u0 - kn * n0, rzz = ku * u1 - kn * n1;
-                // all bounds (ray.py:225-230)
-                fast &= !((xr < e.range_min[0]) | (xr > e.range_max[0]) | (z_hit < e.range_min[1]) | (z_hit > e.range_max[1]));
-                if (fast) {
-                    // batch 2: the log's addresses (device memory: as the generic pointers they are parked as, the stores
-                    // would be FLAT instructions, which the next LDS read would have to wait for)
-                    const Rt2dRayOut& co = cold->out;
-                    typedef __attribute__((address_space(1))) int32_t* g_i32p;
-                    typedef __attribute__((address_space(1))) uint8_t* g_u8p;
-                    typedef __attribute__((address_space(1))) double* g_f64p;
-                    const g_i32p o_step = (g_i32p)co.reb_step; const g_u8p o_surface = (g_u8p)co.reb_surface;
-                    const g_f64p o_velocity = (g_f64p)co.reb_velocity, o_angle = (g_f64p)co.reb_angle;
-                    const g_f64p o_pos_x = (g_f64p)co.reb_pos_x, o_pos_z = (g_f64p)co.reb_pos_z;
-                    const int64_t n_rays = cold->n;
-                    asm volatile("" :: "v"(o_step), "v"(o_surface), "v"(o_velocity), "v"(o_angle), "v"(o_pos_x), "v"(o_pos_z), "v"(n_rays));
-                    if (log_it) {
-                        const int64_t k = (int64_t)n_reb * n_rays + r;
-                        if (o_step) o_step[k] = i + 1;
-                        if (o_surface) o_surface[k] = hitf ? RT2D_SURFACE_SEDIMENT : RT2D_SURFACE_WATER;
-                        if (o_velocity) o_velocity[k] = c;
-                        if (o_angle) {
-                            const double q = rzz / rx;
-                            o_angle[k] = 1 / sqrt(1 + q * q);                             // ray.py:184,207 (cos of grazing angle)
-                        }
-                        if (o_pos_x) o_pos_x[k] = x;
-                        if (o_pos_z) o_pos_z[k] = z;
-                    }
-                    n_reb += 1;
-                    x_new = xr; z_new = z_hit;
-                    kx = rx; kz = rzz;
-#pragma unroll
-                    for (int k8 = 0; k8 < 8; ++k8) rz[k8] = rh[k8];
+                    for (int k8 = 0; k8 < 8; ++k8) rz[k8] = o.rh[k8];
                     reb_done = true;
                 }
             }
