@@ -178,7 +178,8 @@ int32_t rt2d_layout_summary(const int32_t* n_pts, const int32_t* status, const d
  * C (device, may be NULL) additionally receives the sound speed at every point (ray.py:273).
  * A tile never writes outside [tile_off[t], tile_off[t+1]): points beyond the tile's room are counted in n_pts but
  * not stored.  This allows a single speculative pass over a provisional layout (e.g. the same generous room for
- * every tile) followed by rt2d_traj_layout + rt2d_traj_compact when max(n_pts) fits, instead of count + store. */
+ * every tile) followed by rt2d_traj_layout + rt2d_traj_compact when max(n_pts) fits, instead of count + store.
+ * params->n_steps_max is limited to 8 388 606 here (a lane addresses its tile with a 32-bit byte offset). */
 int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const double* src,
                         const Rt2dParams* params, const double* init_slope, const double* init_mult,
                         const Rt2dRayOut* out, const int64_t* tile_off, double* X, double* Z, double* C,

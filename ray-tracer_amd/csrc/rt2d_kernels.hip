@@ -2740,6 +2740,8 @@ int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const d
     int32_t rc = check_cast(env, angles, n, src, params, init_slope, init_mult, out);
     if (rc) return rc;
     if (!tile_off || !X || !Z) return fail("rt2d_cast_write: tile_off, X and Z are required");
+    // (a lane addresses its tile with a 32-bit byte offset: 512 B per stored point of a ray)
+    if (params->n_steps_max > (1 << 23) - 2) return fail("rt2d_cast_write: at most 8 388 606 steps per ray when trajectories are stored");
     if (n == 0) return 0;
     CastArgs a = make_cast_args(env, angles, n, src, params, init_slope, init_mult, out);
     a.tile_off = tile_off; a.X = X; a.Z = Z; a.C = C;
