@@ -1830,6 +1830,95 @@ __global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_kernel(const
 }
 
 
+// The same running sums for fans with few (tile, frequency) pairs, where rt2d_gain_scan_kernel would leave most of the chip
+// idle (999 rays at one frequency: 16 workgroups): a workgroup takes GAIN_PART_RAYS rays of a tile instead of all 64, so
+// that a chunk (of 1024 / GAIN_PART_RAYS rows) is ONE element per thread (the fifteen loader waves of the kernel above issue five rows each per
+// chunk, and their instructions, not memory, are what a chunk waits for) and 64 / GAIN_PART_RAYS times as many CUs take part.  The first
+// GAIN_PART_RAYS threads run the sums besides their share of the loading.  Same additions in the same order.
+#define GAIN_PART_RAYS 8        // (999 rays, one frequency: 0.808 / 0.795 / 0.790 / 0.791 / 0.821 ms per heat map with 32 / 16 / 8 / 4 / 2)
+__global__ void __launch_bounds__(GAIN_SCAN_THREADS) rt2d_gain_scan_part_kernel(const GainArgs a) {
+    constexpr int R = GAIN_PART_RAYS, ROWS = GAIN_SCAN_THREADS / R;
+    extern __shared__ __attribute__((aligned(16))) double s_buf[];          // three [ROWS][R] chunks, then the loss table
+    double* s_loss = s_buf + 3 * ROWS * R;                                  // [cap][R] cumulative rebound loss
+    int* s_at = reinterpret_cast<int*>(s_loss + (size_t)a.rebound_cap * R); // [cap][R] first point carrying it
+    const int ray_l = threadIdx.x & (R - 1), row_l = threadIdx.x / R;
+    const bool scanner = threadIdx.x < R;
+    const int col = (int)blockIdx.z * R + ray_l;                            // the ray's lane in its tile
+    const int64_t tile = blockIdx.x;
+    const int64_t r = tile * RT2D_WAVE + col;
+    const int fi = blockIdx.y;
+    const int64_t t0 = a.tile_off[tile];
+    const int np = (r < a.n) ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
+    int n_rows = np;                                                        // rows of the longest of these R rays
+    for (int off = R / 2; off > 0; off >>= 1) n_rows = max(n_rows, __shfl_xor(n_rows, off));
+    n_rows = max(n_rows, 1);
+    double* G = a.G + (int64_t)fi * a.total + t0;
+    const int nreb = (r < a.n) ? min(a.n_rebounds[r], a.rebound_cap) : 0;
+    {
+        const double fr = a.freqs[fi];
+        const double* gtab = a.blob + a.env.gain_off;
+        for (int k = row_l; k < a.rebound_cap; k += ROWS) {
+            if (k < nreb) {
+                int64_t kk = (int64_t)k * a.n + r;
+                double wavelength = a.reb_velocity[kk] / fr;
+                double rc = (a.reb_surface[kk] == RT2D_SURFACE_SEDIMENT)
+                    ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, a.env.imp, a.reb_pos_z[kk], nullptr))
+                    : rt2d_refcoef_surface(wavelength, a.reb_angle[kk]);
+                s_loss[k * R + ray_l] = 10 * log10(rc);
+                s_at[k * R + ray_l] = a.reb_step[kk] + 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (scanner) {
+        double A = 0.0;
+        for (int k = 0; k < nreb; ++k) { A += s_loss[k * R + ray_l]; s_loss[k * R + ray_l] = A; }
+    }
+    __syncthreads();
+    int next_reb = 0;
+    int next_reb_at = (nreb > 0) ? s_at[ray_l] : 0x7fffffff;
+    double A = 0.0, S = 0.0;
+    const int n_chunks = (n_rows + ROWS - 1) / ROWS;
+    double reg = G[(int64_t)min(row_l, n_rows - 1) * RT2D_WAVE + col];
+    for (int it = 0; it < n_chunks + 2; ++it) {
+        if (it < n_chunks) {
+            const int sx = it * ROWS + row_l;
+            s_buf[(it % 3) * (ROWS * R) + row_l * R + ray_l] = (sx >= 1 && sx < np) ? reg : 0.0;
+            reg = G[(int64_t)min((it + 1) * ROWS + row_l, n_rows - 1) * RT2D_WAVE + col];     // the next chunk on its way
+        }
+        if (it >= 2) {
+            const int sx = (it - 2) * ROWS + row_l;
+            if (sx < np) {
+                while (sx >= next_reb_at) {
+                    A = s_loss[next_reb * R + ray_l];
+                    ++next_reb;
+                    next_reb_at = (next_reb < nreb) ? s_at[next_reb * R + ray_l] : 0x7fffffff;
+                }
+                G[(int64_t)sx * RT2D_WAVE + col] = s_buf[((it - 2) % 3) * (ROWS * R) + row_l * R + ray_l] + A;
+            }
+        }
+        if (scanner && it >= 1 && it <= n_chunks) {
+            double* buf = s_buf + ((it - 1) % 3) * (ROWS * R);
+            for (int rb = 0; rb < ROWS; rb += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = buf[(rb + u) * R + ray_l];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { S += v[u]; v[u] = S; }       // ray.py:347
+#pragma unroll
+                for (int u = 0; u < 16; ++u) buf[(rb + u) * R + ray_l] = v[u];
+            }
+        }
+        __syncthreads();
+    }
+    if (scanner && r < a.n && a.G_end) {
+        double A_end = 0.0;                              // loss in force at the last point
+        for (int k = 0; k < nreb && s_at[k * R + ray_l] <= np - 1; ++k) A_end = s_loss[k * R + ray_l];
+        a.G_end[(int64_t)fi * a.n + r] = S + A_end;
+    }
+}
+
+
 // Which kernel bins which ray of a fan for the one-pass heat map (RayFan.fused_mask, evaluated on the device so that the
 // host need not wait for the cast): m[r] = 1 for the rays rt2d_gain_heatmap_kernel can bin (no error, x never decreases,
 // bounding box inside the map, at most 8 rows per column by the slope bound), 2 for the other error-free rays, 0 for the
@@ -2932,8 +3021,18 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
                                     : fch == 2 ? rt2d_gain_dg_kernel<2> : rt2d_gain_dg_kernel<1>;
         ALLOW_LDS(k1, lds);
         hipLaunchKernelGGL(k1, grid1, dim3(256), lds, (hipStream_t)stream, a);
-        ALLOW_LDS(rt2d_gain_scan_kernel, scan_lds);
-        hipLaunchKernelGGL(rt2d_gain_scan_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs), dim3(GAIN_SCAN_THREADS), scan_lds, (hipStream_t)stream, a);
+        static const int part_env = getenv("RT2D_GAIN_SCAN_PART") ? atoi(getenv("RT2D_GAIN_SCAN_PART")) : -1;    // experiments: 0 / 1
+        if (part_env == 1 || (part_env != 0 && n_tiles * (int64_t)n_freqs * (RT2D_WAVE / GAIN_PART_RAYS) <= 512)) {
+            // few (tile, frequency) pairs: a part of a tile's rays per workgroup, all of them resident at once
+            // (rt2d_gain_scan_part_kernel)
+            const size_t part_lds = 3 * (size_t)GAIN_SCAN_THREADS * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * GAIN_PART_RAYS * 12;
+            ALLOW_LDS(rt2d_gain_scan_part_kernel, part_lds);
+            hipLaunchKernelGGL(rt2d_gain_scan_part_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs, RT2D_WAVE / GAIN_PART_RAYS),
+                               dim3(GAIN_SCAN_THREADS), part_lds, (hipStream_t)stream, a);
+        } else {
+            ALLOW_LDS(rt2d_gain_scan_kernel, scan_lds);
+            hipLaunchKernelGGL(rt2d_gain_scan_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs), dim3(GAIN_SCAN_THREADS), scan_lds, (hipStream_t)stream, a);
+        }
         HIP_OK(hipGetLastError());
         return 0;
     }
