@@ -572,7 +572,11 @@ def main():
                 'atomics_per_s': None if pb['atomics'] is None else pb['atomics'] / t_bin,
                 'points_per_atomic': None if not pb['atomics'] else sl / pb['atomics'], 'pmc_source': pb['source']}
         # the stored fan through the product API (its default for a fan this big: the one-pass map, queued without waiting)
-        product_step(rt, env, source, big_angles)
+        # (warm-up: TWO fans alive at once, as in the loop below, where the previous fan is only released when the next one
+        # has been built -- otherwise the loop's first step may pay for a fresh 68 GB of address space from the driver)
+        warm_a = product_step(rt, env, source, big_angles)
+        warm_b = product_step(rt, env, source, big_angles)
+        del warm_a, warm_b
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(args.large_steps):
             fan_p2, hm_p2 = product_step(rt, env, source, big_angles)
