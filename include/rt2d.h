@@ -342,7 +342,10 @@ int32_t rt2d_heatmap_finalize_multi(const double* H, const int32_t* shape, int32
  * library routine.  Limit: n <= 1048576 rays (RT2D_NOALLOC_MAX_RAYS); more is rejected with an error, nothing is run.
  * Every call on a GPU shares that GPU's list (its header words are cleared at the start of each call): calls that
  * overlap on one GPU (different streams, different threads) race -- serialise them.  On return nothing is reported
- * about the number of rays the general kernel handled (rt2d_heatmap_accumulate's work[0]). */
+ * about the number of rays the general kernel handled (rt2d_heatmap_accumulate's work[0]).
+ * Set-up: the per-device address of the built-in array is taken by rt2d_env_create on the device the environment is
+ * created on; on a device where no environment was ever created, the FIRST call takes it itself (hipGetSymbolAddress,
+ * which may load the code object) and must therefore be made outside stream capture. */
 int32_t rt2d_heatmap_accumulate_noalloc(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                         const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                         const int32_t* res, const int32_t* shape,

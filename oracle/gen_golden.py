@@ -4,7 +4,7 @@ Runs only in the build container (the reference does not travel to the GPU box);
 writes are data only: inputs (environment tables, fan definition, parameters) and the reference's
 outputs (per-ray integers, sub-sampled trajectories, end-of-ray scalars, gains, heat maps).
 
-    python oracle/gen_golden.py [c1 c2 c3 c4 c5 t2]        (default: all)
+    python oracle/gen_golden.py [c1 c2 c3 c4 c5 t2 t3 f5]      (default: all)
 
 Floors / ceilings are handed to the reference as oracle.LinearFloor callables, i.e. the very
 piecewise-linear tables the device reads, so both sides integrate over one sea floor
@@ -292,6 +292,18 @@ def t2():
     save('t2_single', spec, fan_dict([0., 0.], [-1.], freqs), out)
 
 
+def t3():
+    """tests_3.ipynb cells 2-3, 14, 16: the 10-ray fan at the reference's DEFAULT step sizes (dx_max = 10, dz_max = 0.1,
+    100 000 steps, no rebound limit: preferences.py:6-9), the fan behind its second published timing ("2 m 10.7 s").
+    Float source (the notebook's integer source truncates the stored trajectory, SURVEY trap 7)."""
+    fl = tabulated(lambda x: -1000. + 0.001 * x, 0., 100000., 4001)
+    ce = LinearFloor([0., 100000.], [0., 0.])
+    spec = env_spec(fl, ce, [0., -1000.], [100000., 0.])
+    angles = np.linspace(-0.5, 0.3, 10)
+    out, _ = run_fan(make_env(spec), [0., -200.], angles, [1, 1000.])
+    save('t3_default10', spec, fan_dict([0., -200.], angles, [1, 1000.]), out)
+
+
 def synth_signal(n=4096, sample_rate=8000.):
     """Deterministic test signal for the eigenray filter (the reference's WAV inputs are absent from its tree): a
     linear chirp 50 Hz -> 3 kHz plus seeded noise, Hann-tapered."""
@@ -332,7 +344,7 @@ def f5():
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ['c1', 'c2', 'c3', 'c4', 'c5', 't2', 'f5']
+    which = sys.argv[1:] or ['c1', 'c2', 'c3', 'c4', 'c5', 't2', 't3', 'f5']
     for w in which:
         t = time.time()
         globals()[w]()

@@ -64,18 +64,31 @@ def _write_build_info():
                                                          text=True, stderr=subprocess.DEVNULL).strip())
     except (OSError, subprocess.CalledProcessError):
         pass
-    try:
-        with open(os.path.join(_HERE, 'BUILD_INFO.json'), 'w') as f:
+    try:                                                    # (atomic: N ranks may import at once)
+        path = os.path.join(_HERE, 'BUILD_INFO.json')
+        tmp = f'{path}.{os.getpid()}.tmp'
+        with open(tmp, 'w') as f:
             json.dump(info, f)
+        os.replace(tmp, path)
     except OSError:
         pass
+
+
+def _build_info_is_current():
+    import json
+    try:
+        with open(os.path.join(_HERE, 'BUILD_INFO.json')) as f:
+            return json.load(f).get('source_sha256') == source_hash()
+    except (OSError, ValueError):
+        return False
 
 
 def build(force=False, verbose=False):
     """Compile the HIP kernels for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     deps = SOURCES + HEADERS
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
-        _write_build_info()
+        if not _build_info_is_current():                   # (only when the stamp names other sources: no git calls, no
+            _write_build_info()                            # rewrite on every import)
         return SO_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17',

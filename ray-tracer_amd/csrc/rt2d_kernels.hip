@@ -2615,6 +2615,8 @@ static int32_t pack_table(std::vector<double>& blob, const Rt2dTable* tabs, int 
     return 0;
 }
 
+extern "C++" { static int32_t noalloc_scratch(int32_t** out); }
+
 int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
     if (!d || !env_out) return fail("rt2d_env_create: null argument");
     rt2d_env_s* env = new rt2d_env_s();
@@ -2654,6 +2656,10 @@ int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
     if (hipMemcpy(env->blob, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(env->blob); delete env; return fail("hipMemcpy of the table blob failed");
     }
+    // rt2d_heatmap_accumulate_noalloc: the per-device address of its scratch array is taken HERE, on the device the
+    // environment lives on (hipGetSymbolAddress may load the code object, which is not legal under stream capture), so that a
+    // first rt2d_heatmap_accumulate_noalloc on this device makes no set-up call of its own
+    { int32_t* unused = nullptr; if ((rc = noalloc_scratch(&unused))) { (void)hipFree(env->blob); delete env; return rc; } }
     *env_out = env;
     return 0;
 }
@@ -3146,6 +3152,18 @@ int32_t rt2d_target_products(rt2d_env_t env, const double* X, const double* Z, c
 }
 
 extern "C++" {
+static int knob_pow2(const char* name, int dflt, int lo, int hi) {
+    const char* v = getenv(name);
+    if (!v) return dflt;
+    const int k = atoi(v);
+    return (k >= lo && k <= hi && (k & (k - 1)) == 0) ? k : dflt;
+}
+static int knob_even(const char* name, int dflt, int lo, int hi) {
+    const char* v = getenv(name);
+    if (!v) return dflt;
+    const int k = atoi(v);
+    return (k >= lo && k <= hi && (k & 1) == 0) ? k : dflt;
+}
 static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                        const int32_t* res, const int32_t* shape,
@@ -3184,8 +3202,10 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     a.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
     a.nx = shape[0]; a.nz = shape[1]; a.H = H; a.n_dropped = n_dropped;
     // LDS per one-ray workgroup: cap * 8 B of hash + cell_cap * 4 B of cached cells; it decides how many rays a CU works on
-    static const int hm_cap = getenv("RT2D_HM_CAP") ? atoi(getenv("RT2D_HM_CAP")) : 4096;
-    static const int hm_cells = getenv("RT2D_HM_CELLS") ? atoi(getenv("RT2D_HM_CELLS")) : 4096;
+    // (development knobs: the hash and the LDS table are addressed with masks, the doubles behind the cached cells must stay
+    // 8-byte aligned -- anything but a power of two / an even count falls back to the default)
+    static const int hm_cap = knob_pow2("RT2D_HM_CAP", 4096, 64, 8192);
+    static const int hm_cells = knob_even("RT2D_HM_CELLS", 4096, 64, 16384);
     a.cap = hm_cap; a.cell_cap = hm_cells;
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
     // below ~6000 rays the latter finishes first (measured with the rows of a tile shared by up to 16 waves)
@@ -3205,7 +3225,7 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         // 11.6 M atomics but one workgroup less per CU and 2.7 ms) -- these rays are the ones that scatter, their
         // neighbours share fewer cells than the rays of the tile kernel do
         a.group = (int32_t)group;
-        static const int acc_env = getenv("RT2D_HM_ACC") ? atoi(getenv("RT2D_HM_ACC")) : 1024;
+        static const int acc_env = knob_pow2("RT2D_HM_ACC", 1024, 64, 4096);
         a.acc_cap = (group > 1 && n_freqs == 0) ? acc_env : 0;
         if (a.acc_cap && a.cell_cap > 2048) a.cell_cap = 2048;
         const int64_t groups = (items_max + group - 1) / group;
@@ -3329,6 +3349,15 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
                                int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream) {
     if (n_rest < 0 || (n_rest > 0 && (!rest_list || !g_slot || !G_rest || g_room <= 0)))
         return fail("rt2d_gain_heatmap_rest: rest_list, g_slot, G_rest and g_room describe the rays of ray_mask value 2");
+    // the same argument checks as gain_heatmap_impl, BEFORE anything is dereferenced or queued on either stream
+    if (!env || !X || !Z || !tile_off || !n_pts || !reb || !res || !shape || !H) return fail("rt2d_gain_heatmap_rest: null argument");
+    if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
+        return fail("rt2d_gain_heatmap_rest: the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) is required");
+    if (n < 0 || rebound_cap < 0) return fail("rt2d_gain_heatmap_rest: negative count");
+    if (!(freq > 0)) return fail("rt2d_gain_heatmap_rest: freq must be positive");
+    if (res[0] <= 0 || res[1] <= 0 || res[0] >= (1 << 20) || res[1] >= (1 << 20)) return fail("rt2d_gain_heatmap_rest: bad resolution");
+    if (shape[0] <= 0 || shape[1] <= 0 || (int64_t)shape[0] * shape[1] >= (1ll << 31)) return fail("rt2d_gain_heatmap_rest: bad shape");
+    if (n == 0) return 0;
     static const bool side_on = !(getenv("RT2D_REST_SIDE_STREAM") && atoi(getenv("RT2D_REST_SIDE_STREAM")) == 0);
     if (n_rest == 0 || !side_on || !(loss_ws && rebound_cap > 0)) {
         // one stream: the pass writes the side rays' gain, the general kernel follows it
@@ -3355,8 +3384,6 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
         a.env = env->dev; a.blob = env->blob; a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
         a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
         a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1;
-        if (!reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
-            return fail("rt2d_gain_heatmap_rest: the rebound log is required");
         const int64_t pairs = n * rebound_cap;
         if (pairs > 0)
             hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, main, a, loss_ws, freq);

@@ -129,7 +129,7 @@ def allgather_topk(dist_local, angles_local, k, index_local=None):
         dev = d.device
         count = torch.tensor([d.numel()], dtype=torch.int64, device=dev)
         _all_reduce(count, dist.ReduceOp.MAX)
-        m = int(count.item())
+        m = max(1, int(count.item()))          # (no rank has a valid distance: still a non-empty gather; the NaN padding is filtered by select)
         cand = torch.full((3, m), float('nan'), dtype=torch.float64, device=dev)
         cand[0, :d.numel()], cand[1, :d.numel()], cand[2, :d.numel()] = d, a, idx
         if cand.is_cuda and dist.get_backend() == 'gloo':

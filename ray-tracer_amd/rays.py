@@ -187,7 +187,7 @@ class RayFan:
         p.power_cutoff, p.cutoff_freq = float(self.kw['power_cutoff']), float(self.kw['cutoff_freq'])
         return p
 
-    def _cast(self, init, store_c, known_n_pts=None, alloc_only=False):
+    def _cast(self, init, store_c, known_n_pts=None, alloc_only=False, known_reb_max=None):
         torch = _torch()
         kwargs_keep_log = self.keep_log
         L = _lib.lib()
@@ -369,8 +369,13 @@ class RayFan:
             # pass 2: store trajectories, the rebound log and the post-pass scalars
             out = full_out()
             if known_n_pts is not None:
+                # the rebound counts of these rays are known too (subset()): the log is sized by them, so it cannot
+                # overflow -- nothing behind this pass would act on an overflow
                 nrm_k = int(self.kw['n_rebounds_max'])
-                alloc_log(out, nrm_k + 1 if nrm_k > -1 else REBOUND_LOG_CAP_DEFAULT)
+                if known_reb_max is not None:
+                    alloc_log(out, max(1, int(known_reb_max)))
+                else:
+                    alloc_log(out, nrm_k + 1 if nrm_k > -1 else REBOUND_LOG_CAP_DEFAULT)
             else:
                 alloc_log(out, max(1, int(self.n_rebounds.max().item())))
             self.X = torch.empty(self.total, **f64)
@@ -468,9 +473,12 @@ class RayFan:
             # a subset of a scalars-only fan (subset()): its trajectories are cast now, in ONE storing pass -- the point
             # counts are already known, so the exact layout can be built before the pass
             known = self.n_pts
+            reb_max = int(self.n_rebounds.max().item()) if self.n else 0
             self.store, self._lazy_store = True, False
             self._host = {}
-            self._cast(self._init_host, False, known_n_pts=known)
+            self._cast(self._init_host, False, known_n_pts=known, known_reb_max=reb_max)
+            if self._summary is not None and bool(self._summary[2]):
+                raise _lib.Rt2dError('internal: a rebound log sized by the known rebound counts overflowed')
 
     def subset(self, indices):
         """The rays `indices` of a fan cast with store=False as a fan of their own: per-ray scalars are copied, nothing is

@@ -98,3 +98,30 @@ def test_chunk_that_outgrows_its_provisional_layout(rt, small_chunks, monkeypatc
     monkeypatch.undo()
     _, _, Hs = _stored(rt, g, env, **kw)
     _same_map(Hc.cpu().numpy(), Hs)
+
+
+def test_counted_chunks_size_the_rebound_log_by_the_known_counts(rt, small_chunks):
+    """a store=False fan that was counted before casts each chunk straight into its exact layout (subset() ->
+    _need_store()).  With n_rebounds_max = -1 the rebound log of that pass used to be the default 64 entries; rays with
+    more rebounds then carried the log-overflow status and silently fell out of the map.  Shallow water (100 m), steep
+    rays, no rebound limit: well over 64 rebounds per ray; same map as the stored fan, no ray lost."""
+    import torch
+    xs = np.linspace(0., 20000., 201)
+    env = rt.Environment2D((xs, np.full_like(xs, -100.)), (np.array([0., 20000.]), np.array([0., 0.])),
+                           np.array([0., -101.]), np.array([20000., 1.]))
+    source = np.array([0., -50.])
+    angles = np.linspace(-1.2, -0.4, 600)
+    kw = dict(dx_max=50., dz_max=25., n_rebounds_max=-1, n_steps_max=4000)
+    counted = rt.RayFan(env, source, angles, store=False, **kw)
+    assert int(counted.n_rebounds.max().item()) > 64
+    shape = (402, 6)
+    Hc = torch.zeros(shape[0] * shape[1], dtype=torch.float64, device='cuda')
+    dropped_c = torch.zeros(1, dtype=torch.int64, device='cuda')
+    assert counted.heatmap_accumulate_chunked(Hc, (50, 25), shape, dropped=dropped_c)
+    stored = rt.RayFan(env, source, angles, **kw)
+    assert np.array_equal(stored.host('n_rebounds'), counted.host('n_rebounds'))
+    assert int((stored.host('status') != 0).sum()) == 0
+    Hs = torch.zeros_like(Hc)
+    stored.heatmap_accumulate(Hs, (50, 25), shape, ray_mask=(stored.status == 0).to(torch.uint8))
+    assert float(Hs.sum()) > 0
+    _same_map(Hc.cpu().numpy(), Hs.cpu().numpy())

@@ -65,7 +65,7 @@ def test_dist_kernel(rt, orc):
         assert d0[i] == _oracle_post(orc, oenv, rays[i], target=np.array([0., -100.]))
 
 
-@pytest.mark.parametrize('name', ['c4_multifreq', 'c2_fan999', 't2_single'])
+@pytest.mark.parametrize('name', ['c4_multifreq', 'c2_fan999', 't2_single', 't3_default10'])
 def test_gain_vs_reference(rt, name):
     """populate_NEW against the reference's G (end values and sampled points)."""
     g = common.load(name)
@@ -119,7 +119,7 @@ def test_gain_vs_oracle_same_points(rt, orc):
 
 
 @pytest.mark.parametrize('fast', [True, 'nohint', False])
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999', 't3_default10'])
 def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
     """Binning in isolation: oracle heat map over the GPU's own points and gains -> every cell equal to 1e-12.
     fast=True: coalesced tile kernel + general kernel for the queued rays; fast=False: general kernel only."""
@@ -149,7 +149,7 @@ def test_heatmap_kernel_vs_oracle_same_points(rt, orc, name, fast):
         assert np.abs(out - plot_ref).max() < 1e-12
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999', 't3_default10'])
 def test_heatmap_vs_reference(rt, name):
     """Whole pipeline against the reference's heat map; bin-edge disagreements are counted and bounded."""
     g = common.load(name)

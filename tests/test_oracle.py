@@ -12,14 +12,14 @@ from common import TRAJ_RTOL, TRAJ_RTOL_WORST, KNIFE_EDGE_M
 @pytest.fixture(scope='module')
 def fans(orc):
     out = {}
-    for name in ('c1_flat250', 'c2_fan999', 'c3_bathy999', 'c4_multifreq', 't2_single'):
+    for name in ('c1_flat250', 'c2_fan999', 'c3_bathy999', 'c4_multifreq', 't2_single', 't3_default10'):
         g = common.load(name)
         env = common.oracle_env(orc, g)
         out[name] = (g, env, common.oracle_fan(orc, env, g))
     return out
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999', 'c4_multifreq', 't2_single'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999', 'c4_multifreq', 't2_single', 't3_default10'])
 def test_discrete_outcomes_and_trajectories(fans, name):
     g, env, rays = fans[name]
     err = g['error'] != 0
@@ -57,7 +57,7 @@ def test_discrete_outcomes_and_trajectories(fans, name):
     assert np.percentile(errs, 99) < TRAJ_RTOL and errs.max() < TRAJ_RTOL_WORST
 
 
-@pytest.mark.parametrize('name', ['c2_fan999', 'c4_multifreq', 't2_single'])
+@pytest.mark.parametrize('name', ['c2_fan999', 'c4_multifreq', 't2_single', 't3_default10'])
 def test_gain(orc, fans, name):
     g, env, rays = fans[name]
     ok = (g['error'] == 0) & (np.array([r.steps for r in rays]) == g['steps'])
@@ -73,7 +73,7 @@ def test_gain(orc, fans, name):
             assert np.all(np.abs(G[g['sample_idx'][i]][m] - ref_s[m]) <= 1e-7 * np.maximum(1e-3, np.abs(ref_s[m])))
 
 
-@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999'])
+@pytest.mark.parametrize('name', ['c1_flat250', 'c2_fan999', 'c3_bathy999', 't3_default10'])
 def test_heatmap(orc, fans, name):
     g, env, rays = fans[name]
     good = [r for r in rays if r.status == 0]
@@ -144,8 +144,9 @@ def test_sensitivity_justifies_worst_case_tolerance(orc, fans):
         if r2.steps == rays[i].steps:
             worst = max(worst, common.rel_err(r2.XZ, rays[i].XZ).max())
     ulp = np.spacing(0.225) / 0.225
+    print(f'one ulp of the launch angle moves the most sensitive c2 rays by {worst:.2e} relative ({worst / ulp:.1e} x)')
     assert worst > 1e3 * ulp            # amplification of at least 1000x is observed
-    assert worst < TRAJ_RTOL_WORST
+    assert worst < 1e-6                 # (a demonstration of the sensitivity, not a parity bound)
 
 
 def test_edge_cases(orc):
