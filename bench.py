@@ -356,6 +356,100 @@ def ray_steps_of(n_pts, status):
     return int((n_pts[ok] - 1).sum().item())
 
 
+def lane_utilisation(n_pts):
+    """sum(n_pts) / sum over 64-ray tiles of 64 * max(n_pts): the share of a wave's lane-steps that belong to a ray
+    which is still alive (a wave lives until its longest ray ends)."""
+    import torch
+    n = int(n_pts.numel())
+    if n == 0:
+        return None
+    p = torch.cat([n_pts, n_pts.new_zeros((-n) % 64)]).view(-1, 64).to(torch.int64)
+    return float(p.sum().item()) / float(64 * p.amax(dim=1).sum().item())
+
+
+def default_resolution_block(rt, torch, env_c2, device, rays, reps=2):
+    """Fans at the reference's DEFAULT step sizes (preferences.py:6-9: dx_max 10, dz_max 0.1, 100 000 steps, no rebound
+    limit).  (a) the 10-ray fan of tests_3.ipynb cells 2-3, 14, 16 -- the reference's second published timing, 2 m 10.7 s --
+    pinned to the reference by tests/golden/t3_default10.npz; (b) a C2 fan of `rays` rays through
+    Simulation2D.cast(store=False) + heatmap(): the default path, and the other no-trajectory path beside it."""
+    from ray_tracer_amd import rays as rays_mod
+    out = {'step_sizes': 'dx_max 10, dz_max 0.1, n_steps_max 100000, n_rebounds_max -1 (preferences.py:6-9)'}
+
+    def timed(fn, k):
+        fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(k):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k, r
+
+    xs = np.linspace(0., 100000., 4001)
+    env3 = rt.Environment2D((xs, -1000. + 0.001 * xs), (np.array([0., 100000.]), np.array([0., 0.])),
+                            np.array([0., -1000.]), np.array([100000., 0.]))
+    src3, ang3 = np.array([0., -200.]), np.linspace(-0.5, 0.3, 10)
+
+    def t3(with_map):
+        sim = rt.Simulation2D(env3, src3)
+        fan = sim.cast(ang3)
+        if with_map:
+            sim.heatmap(resolution=list(RES), as_tensor=True)
+        fan.validate()
+        return fan
+    t_cast, fan3 = timed(lambda: t3(False), reps)
+    t_map, _ = timed(lambda: t3(True), reps)
+    ref_s = None
+    gold = os.path.join(ROOT, 'tests', 'golden', 't3_default10.npz')
+    if os.path.exists(gold):
+        ref_s = float(np.load(gold)['ref_seconds'])
+    out['tests3_fan10'] = {
+        'workload': 'tests_3.ipynb: floor -1000 + 0.001 x over 100 km, source (0, -200), 10 rays linspace(-0.5, 0.3), defaults',
+        'ray_steps': fan3.ray_steps(), 'ms_per_cast': t_cast * 1e3, 'ms_per_cast_plus_heatmap': t_map * 1e3,
+        'passes': fan3.passes, 'lane_utilisation': lane_utilisation(fan3.n_pts),
+        'reference_s_published': 130.7, 'reference_s_published_source': 'tests_3.ipynb cell 16 (author\'s machine, 1 core)',
+        'reference_s_build_container': ref_s, 'reference_s_build_container_source': 'oracle/gen_golden.py t3 (ref_seconds in the fixture)',
+        'note': '10 rays = one wave of 10 lanes: 100 000 dependent steps of a lone wave (latency, not throughput)'}
+
+    n = int(rays)
+    angles = torch.from_numpy(-(np.arange(n) + 1) * (0.999 / n)).to(device)
+    source = np.array([0., 0.])
+
+    def run(path):
+        old = rays_mod.CHUNKED_MIN_RAYS
+        if path == 'fused':
+            rays_mod.CHUNKED_MIN_RAYS = 1 << 60
+        elif path == 'chunked':
+            rays_mod.CHUNKED_MIN_RAYS = 1
+        try:
+            sim = rt.Simulation2D(env_c2, source)
+            fan = sim.cast(angles, store=False)
+            hm = sim.heatmap(resolution=list(RES), cutoff=CUTOFF, reduction_power=.5, as_tensor=True)
+            return fan, hm
+        finally:
+            rays_mod.CHUNKED_MIN_RAYS = old
+    t_def, (fan, hm) = timed(lambda: run('default'), reps)
+    steps = ray_steps_of(fan.n_pts, fan.status)
+    default_is_fused = n < rays_mod.CHUNKED_MIN_RAYS
+    other = 'chunked' if default_is_fused else 'fused'
+    t_other, (fan_o, hm_o) = timed(lambda: run(other), 1)
+    blk = {
+        'workload': f'C2 environment, {n} rays -(j+1) 0.999/{n} rad, defaults, Simulation2D.cast(store=False) + heatmap()',
+        'rays': n, 'ray_steps': steps, 's_per_heatmap': t_def, 'ray_steps_per_s': steps / t_def, 'passes': fan.passes,
+        'path': ('fused kernel (rt2d_cast_heatmap: count pass, then cast -> gain -> binning with nothing stored; the rays it '
+                 'cannot bin go through the stored path beside it)' if default_is_fused else
+                 'chunked (cast with trajectories -> one-pass gain + bin -> drop)'),
+        'why': 'a ray has 100 001 points at these step sizes: trajectories are 1.6 MB per ray and every point is written and '
+               'read once (chunked), against no trajectory traffic at all (fused); measured both ways below',
+        'chunks': 0 if default_is_fused else -(-n // fan._chunk_rays()),
+        'rays_through_the_stored_side_path': int(fan.last_slow_rays),
+        'lane_utilisation': lane_utilisation(fan.n_pts),
+        'fp64_vector_frac_at_48_flop_per_step': steps * FLOP_PER_STEP / t_def / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+        'stop_code_histogram': torch.bincount(fan.stop_code.to(torch.int64), minlength=9).tolist(),
+        'other_path': {'path': other, 's_per_heatmap': t_other, 'chunks': -(-n // fan_o._chunk_rays()) if other == 'chunked' else 0,
+                       'max_abs_diff_of_the_maps': float((hm - hm_o).abs().max().item())}}
+    out['c2_fan'] = blk
+    return out
+
+
 def cpu_baseline(seconds=12.0):
     """oracle/rt2d_oracle.c (scalar port of the reference's algorithm) on this host, 1 core, same C2 fan."""
     from oracle import oracle as orc
@@ -389,6 +483,15 @@ def cpu_baseline(seconds=12.0):
             dtt = time.perf_counter() - t0
             if dtt >= seconds / 3:
                 break
+    # the 10-ray fan of tests_3.ipynb at the reference's default step sizes (bench block default_resolution), same port, 1 core
+    xs3 = np.linspace(0., 100000., 4001)
+    oenv3 = orc.OracleEnv(orc.LinearFloor(xs3, -1000. + 0.001 * xs3), orc.LinearFloor([0., 100000.], [0., 0.]),
+                          [0., -1000.], [100000., 0.])
+    p3 = orc.make_params()
+    t0 = time.perf_counter()
+    s3, _, _ = orc.run_fan(oenv3, [0., -200.], np.linspace(-0.5, 0.3, 10), p3, freq=1, res=RES)
+    res['tests3_fan10_default_steps'] = {'s_per_heatmap': time.perf_counter() - t0, 'ray_steps': int(s3), 'cores': 1,
+                                         'sample': 'the whole fan once (cast x2 + post + gain@1Hz + heat map)'}
     res['all_cores'] = {'value': s * reps_t / dtt, 'unit': 'ray-steps/s', 'cores': threads, 's_per_heatmap': dtt / reps_t,
                         'sample': f'{reps_t} x the same fan, {threads} threads, one block of rays each, in {dtt:.2f} s'}
     return res
@@ -401,6 +504,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--large-rays', type=int, default=1 << 20, help='rays of the large-fan block (0 = skip)')
     ap.add_argument('--large-steps', type=int, default=3)
+    ap.add_argument('--default-rays', type=int, default=65536, help='rays of the default-step-size C2 fan (0 = skip the block)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--force-collectives', action='store_true',
                     help='run the two all-reduces of the step even in a group of one rank (rehearses RCCL on a 1-GPU box)')
@@ -519,6 +623,30 @@ def main():
     # N > 1: the 1M-ray fan of the single-GPU block below, SHARDED over the ranks (strong scaling: north_star's "1M-ray
     # heat map on 8 GPUs").  Rays are dealt in blocks of 64 (one tile) round-robin, so every rank sees the whole angular
     # range; C1 / C2 as in the headline step.  Timed like the headline: barrier, K steps, barrier, max over ranks.
+    # N > 1: the literal BASELINE metric -- the 999-ray 20-rebound fan ITSELF dealt over the N ranks (strong scaling: ray j on
+    # rank j % N), C1 and C2 included, through the product API; timed like the headline (barrier, K steps, barrier, max
+    # over ranks).  999 rays are latency-bound on one GPU already: more GPUs shorten nothing but the longest wave's queue.
+    if world > 1:
+        angles999 = -(np.arange(n_fan) + 1) / 1000.0
+        for _ in range(max(1, min(args.warmup, 3))):
+            product_step(rt, env, source, angles999, distributed=True)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fan_s9, hm_s9 = product_step(rt, env, source, angles999, distributed=True)
+        barrier(); dt9 = time.perf_counter() - t0
+        from ray_tracer_amd import parallel
+        t9 = torch.tensor([dt9, float(ray_steps_of(fan_s9.n_pts, fan_s9.status))], dtype=torch.float64, device=device)
+        t9_max = parallel._all_reduce(t9.clone(), dist.ReduceOp.MAX)
+        t9_sum = parallel._all_reduce(t9.clone(), dist.ReduceOp.SUM)
+        if rank == 0:
+            dt9 = float(t9_max[0].item())
+            result['fan999_strong'] = {
+                'workload': 'c2_fan999 (999 rays, 20 rebounds) dealt over the ranks, ray j on rank j % N; C1 + C2 included',
+                'rays_total': n_fan, 'rays_rank0': int(fan_s9.n), 'scaling': 'strong', 'ray_steps_total': float(t9_sum[1].item()),
+                's_per_heatmap': dt9 / args.steps, 'value': float(t9_sum[1].item()) * args.steps / dt9, 'unit': 'ray-steps/s',
+                'heatmap_shape': list(hm_s9.shape)}
+        del fan_s9, hm_s9
+
     if args.large_rays > 0 and world > 1:
         nL = args.large_rays
         tiles = np.arange(rank, (nL + 63) // 64, world)
@@ -540,7 +668,12 @@ def main():
             result['large_fan_sharded'] = {
                 'rays_total': nL, 'rays_per_gpu': int(len(jj)), 'scaling': 'strong', 'ray_steps_total': float(ts_sum[1].item()),
                 'value': float(ts_sum[1].item()) * args.large_steps / dts, 'unit': 'ray-steps/s',
-                's_per_heatmap': dts / args.large_steps, 'stage_ms_rank0': stages_s.summary(), 'heatmap_shape': list(hm_s.shape)}
+                's_per_heatmap': dts / args.large_steps, 'stage_ms_rank0': stages_s.summary(), 'heatmap_shape': list(hm_s.shape),
+                'lane_utilisation_rank0': lane_utilisation(n_pts_s),
+                'roofline_rank0': roofline_block('rt2d_cast_kernel<WRITE=true>', ray_steps_of(n_pts_s, status_s),
+                                                 stages_s.summary()['cast_store'], None,
+                                                 'no PMC pass of a sharded run is committed (the 1-GPU profile is of the unsharded fan)',
+                                                 note='rank 0\'s storing cast of its share of the fan')}
         del shard_angles
 
     # the same pipeline where the GPU is full (single-GPU block, rank 0 only prints it)
@@ -558,7 +691,7 @@ def main():
         traffic_l, traffic_src_l = pmc_traffic(large=True) if nL == (1 << 20) else (None, 'the committed profile is of the 1 048 576-ray fan')
         result['large_fan'] = {
             'rays': nL, 'ray_steps': sl, 'value': sl * args.large_steps / dtl, 'unit': 'ray-steps/s',
-            's_per_heatmap': dtl / args.large_steps, 'stage_ms': stl,
+            's_per_heatmap': dtl / args.large_steps, 'stage_ms': stl, 'lane_utilisation': lane_utilisation(n_pts_l),
             'roofline': roofline_block('rt2d_cast_kernel<WRITE=true>', sl, stl['cast_store'], traffic_l, traffic_src_l),
         }
         if nL == (1 << 20):
@@ -658,9 +791,34 @@ def main():
                                      f'{length / 1e3:.1f} km cut, depths {float(env_b.floor(np.linspace(0, length, 751)).max()):.0f} '
                                      f'to {float(env_b.floor(np.linspace(0, length, 751)).min()):.0f} m',
                 'ray_steps': sb, 'rays_with_error_status': int((status_b != 0).sum().item()),
+                'lane_utilisation': lane_utilisation(n_pts_b),
                 'value': sb * args.large_steps / dtb, 'unit': 'ray-steps/s', 's_per_heatmap': dtb / args.large_steps,
                 'stage_ms': stages_b.summary(), 'heatmap_shape': list(hm_b.shape)}
         del big_angles
+        # BASELINE config 5 through the product API: EigenraySim2D sweep of --large-rays rays (scalars only), the 1000 best
+        # kept (device top-k), three refine iterations of 5 rays per cone (cast without a rebound limit, as the reference does)
+        def eigen():
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            sim_e = rt.EigenraySim2D(env, source, np.array([40000., -600.]), 1000, 20, n_rays_scan=nL, scan_angle_min=-0.999,
+                                     scan_angle_max=-0.001, dx_max=50., dz_max=25.)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            sim_e.refine(iterations=3, n_rays=5, force_refine=True)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            return sim_e, t1 - t0, t2 - t1
+        eigen()
+        sim_e, t_sweep, t_refine = eigen()
+        cone = sim_e.last_cone_fan
+        result['config5_sweep_refine'] = {
+            'rays_scanned': nL, 'rays_kept': 1000, 'target': [40000., -600.],
+            'sweep_plus_topk_plus_recast_ms': t_sweep * 1e3, 'refine_x3_ms': t_refine * 1e3,
+            'sweep_ray_steps': ray_steps_of(sim_e.scan_fan.n_pts, sim_e.scan_fan.status),
+            'sweep_lane_utilisation': lane_utilisation(sim_e.scan_fan.n_pts),
+            'last_refine_cones': {'rays': int(cone.n), 'ray_steps': ray_steps_of(cone.n_pts, cone.status),
+                                  'lane_utilisation': lane_utilisation(cone.n_pts),
+                                  'longest_ray_points': int(cone.n_pts.max().item())}}
+        del sim_e, cone
+        if args.default_rays > 0:
+            result['default_resolution'] = default_resolution_block(rt, torch, env, device, args.default_rays)
     if rank == 0 and world == 1:
         # "raypower cutoff=0.5" read the other way (SURVEY trap 2): rays END when their power falls below the cutoff --
         # not in the reference's propagate; the opt-in CUTOFF instance of the cast kernel, reported apart from the headline

@@ -2880,6 +2880,8 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     if (waves > (loss ? RT2D_FUSE2_MAX_WAVES : RT2D_FUSE_MAX_WAVES)) waves = loss ? RT2D_FUSE2_MAX_WAVES : RT2D_FUSE_MAX_WAVES;
     static const int waves_env = getenv("RT2D_FUSE_WAVES") ? atoi(getenv("RT2D_FUSE_WAVES")) : 0;
     if (waves_env > 0 && waves_env < waves) waves = waves_env;
+    // (tried for fans of few waves: smaller workgroups so that every CU gets one -- 65 536 rays of 100 000 steps: the kernel
+    // 194 -> 155 ms, but the side rays' stored cast beside it, which then shares its CUs, 91 -> 215 ms: slower overall)
     const int block = waves * RT2D_WAVE;
     const size_t lds = cold + tab_bytes + (size_t)waves * per_wave;
     const int64_t grid = (n + block - 1) / block;
@@ -3018,20 +3020,22 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     // (measured crossovers: one frequency 65536 rays 1.40 -> 1.06 ms, 131072 rays 1.59 -> 1.96 ms; 65536 rays x 8
     // frequencies 4.8 -> 3.7 ms, x 64 frequencies slower again: the scan launches a workgroup per (tile, frequency))
     const bool two_phase = tp ? n <= atoll(tp) : (n <= 64 * 512 || (n <= 90000 && n * (int64_t)n_freqs <= 600000));
-    if (G && two_phase && scan_lds <= RT2D_LDS_BUDGET) {
+    const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
+    static const int part_env = getenv("RT2D_GAIN_SCAN_PART") ? atoi(getenv("RT2D_GAIN_SCAN_PART")) : -1;    // experiments: 0 / 1
+    // few (tile, frequency) pairs: a part of a tile's rays per workgroup, all of them resident at once (rt2d_gain_scan_part_kernel);
+    // its LDS holds the rebound log of 8 rays instead of 64, so it still fits when rays have hundreds of rebounds (no rebound
+    // limit at the reference's default step sizes) -- the ray-sequential loop below needs 1.1 us per point on such fans
+    const bool use_part = part_env == 1 || (part_env != 0 && n_tiles * (int64_t)n_freqs * (RT2D_WAVE / GAIN_PART_RAYS) <= 512);
+    const size_t part_lds = 3 * (size_t)GAIN_SCAN_THREADS * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * GAIN_PART_RAYS * 12;
+    if (G && two_phase && (use_part ? part_lds : scan_lds) <= RT2D_LDS_BUDGET) {
         // small fan: per-point dG on the whole chip, then the running sums (see rt2d_gain_dg_kernel)
-        const int64_t n_tiles = (n + RT2D_TILE - 1) / RT2D_TILE;
         const unsigned split = (unsigned)(n_tiles >= 512 ? 4 : (2048 + n_tiles - 1) / n_tiles);
         dim3 grid1((unsigned)n_tiles, split, (unsigned)((n_freqs + fch - 1) / fch));
         void (*k1)(const GainArgs) = fch == 8 ? rt2d_gain_dg_kernel<8> : fch == 4 ? rt2d_gain_dg_kernel<4>
                                     : fch == 2 ? rt2d_gain_dg_kernel<2> : rt2d_gain_dg_kernel<1>;
         ALLOW_LDS(k1, lds);
         hipLaunchKernelGGL(k1, grid1, dim3(256), lds, (hipStream_t)stream, a);
-        static const int part_env = getenv("RT2D_GAIN_SCAN_PART") ? atoi(getenv("RT2D_GAIN_SCAN_PART")) : -1;    // experiments: 0 / 1
-        if (part_env == 1 || (part_env != 0 && n_tiles * (int64_t)n_freqs * (RT2D_WAVE / GAIN_PART_RAYS) <= 512)) {
-            // few (tile, frequency) pairs: a part of a tile's rays per workgroup, all of them resident at once
-            // (rt2d_gain_scan_part_kernel)
-            const size_t part_lds = 3 * (size_t)GAIN_SCAN_THREADS * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * GAIN_PART_RAYS * 12;
+        if (use_part) {
             ALLOW_LDS(rt2d_gain_scan_part_kernel, part_lds);
             hipLaunchKernelGGL(rt2d_gain_scan_part_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs, RT2D_WAVE / GAIN_PART_RAYS),
                                dim3(GAIN_SCAN_THREADS), part_lds, (hipStream_t)stream, a);

@@ -487,7 +487,12 @@ class RayFan:
         torch = _torch()
         if self.store:
             raise _lib.Rt2dError('subset() is for fans cast with store=False')
-        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=self.device)
+        if hasattr(indices, 'data_ptr'):                      # a device tensor is used where it is
+            idx = indices.to(device=self.device, dtype=torch.int64)
+            if self._angles_host is not None or self._init_host is not None:
+                indices = idx.cpu().numpy()
+        else:
+            idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=self.device)
         sub = object.__new__(RayFan)
         sub.env, sub.source, sub.target, sub.device, sub.kw = self.env, self.source, self.target, self.device, dict(self.kw)
         sub.store, sub.keep_log, sub._lazy_store = False, False, True
@@ -715,13 +720,22 @@ class RayFan:
             side_stream.wait_event(after)                # H is zeroed, the angles are there
         else:
             side_stream.wait_stream(main)
+        # rays longer than the room of a provisional layout (default step sizes: 100 001 points): this fan holds their
+        # point and rebound counts, so the side fan is cast ONCE, straight into its exact layout (subset()), instead of
+        # provisional pass -> overflow -> count -> store
+        long_rays = int(self.kw['n_steps_max']) + 1 > SPECULATIVE_ROOM and not self.__dict__.get('_uncast')
         with torch.cuda.stream(side_stream):
             for c0 in range(0, int(rest.numel()), SIDE_FAN_RAYS):
                 part = rest[c0:c0 + SIDE_FAN_RAYS]
-                init = None if self._init[0] is None else (self._init[0][part].cpu().numpy(), self._init[1][part].cpu().numpy())
-                side = RayFan(self.env, self.source, self.angles_dev[part], target=None, store=True, device=self.device,
-                              init=init, **dict(self.kw))
-                side.validate()                          # (a ray that outgrew the provisional room: cast again, now)
+                if long_rays:
+                    side = self.subset(part)
+                    side.target, side.dist, side.step_target, side.T_target = None, None, None, None
+                    side._need_store()
+                else:
+                    init = None if self._init[0] is None else (self._init[0][part].cpu().numpy(), self._init[1][part].cpu().numpy())
+                    side = RayFan(self.env, self.source, self.angles_dev[part], target=None, store=True, device=self.device,
+                                  init=init, **dict(self.kw))
+                    side.validate()                          # (a ray that outgrew the provisional room: cast again, now)
                 side.heatmap_accumulate(H, res, shape, freq=freq, dropped=dropped, fast=fast, stream=False)
                 del side
         if side_stream is not main:
@@ -736,6 +750,14 @@ class RayFan:
         torch = _torch()
         room = min(int(self.kw['n_steps_max']) + 1, SPECULATIVE_ROOM)
         budget = min(PADDED_BYTES, _free_bytes(self.device) // 3)
+        if not self.__dict__.get('_uncast') and self.n and self.__dict__.get('n_pts') is not None:
+            # a fan that was counted before: its chunks go straight into exact layouts (a tile = its longest ray), plus a
+            # gain array per chunk below STREAM_MIN_RAYS rays -- at the reference's default step sizes a ray has 100 001
+            # points, 2.4 MB of trajectory and gain
+            longest = max(1, int(self.n_pts.max().item()))
+            chunk = max(TILE, int(budget // (longest * 24)) // TILE * TILE)
+            pieces = (self.n + chunk - 1) // chunk
+            return max(TILE, ((self.n + pieces - 1) // pieces + TILE - 1) // TILE * TILE)
         chunk = max(1 << 16, int(budget // (room * 16)) >> 16 << 16)
         pieces = (self.n + chunk - 1) // chunk                     # equal pieces rather than full chunks and a small rest
         return max(TILE, ((self.n + pieces - 1) // pieces + TILE - 1) // TILE * TILE)

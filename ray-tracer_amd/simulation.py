@@ -466,6 +466,7 @@ class EigenraySim2D(Simulation2D):
             # (Without a rebound limit some cone rays run to n_steps_max; storing all of them meant a provisional pass,
             # then a counting and a storing pass of 100 000 steps each, per iteration.)
             fan = RayFan(self.env, self.source, cones.reshape(-1), target=self.target, store=False, **self._prop())
+            self.last_cone_fan = fan                              # (diagnostics: lane utilisation of the cones, bench.py)
             dist = fan.dist.clone()
             dist[fan.status != 0] = float('nan')
             dist = dist.view(k, n_rays).cpu().numpy()

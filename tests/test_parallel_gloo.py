@@ -1,4 +1,4 @@
-"""Multi-process path on CPU: world_size 2 under gloo.  Each rank takes its shard of a fan, bins it (with the
+"""Multi-process path on CPU: world_size 2, 4 and 8 under gloo.  Each rank takes its shard of a fan, bins it (with the
 oracle -- there is no GPU here), and the product's collectives (ray-tracer_amd/parallel.py: plot-range
 all-reduce, heat-map all-reduce, top-k all-gather) must reproduce the single-process result."""
 
@@ -54,19 +54,27 @@ def _worker(rank, world, port, mode, out_dir):
     d_tie, a_tie = _tie_case()
     a_loc, i_loc = parallel.shard_angles(a_tie, mode=mode)
     tie_d, tie_a = parallel.allgather_topk(d_tie[i_loc], a_loc, 3, index_local=i_loc)
+    # no ray of any rank reaches the target abscissa (every distance NaN): an empty answer, not a zero-width gather
+    none_d, none_a = parallel.allgather_topk(np.full(len(a_loc), np.nan), a_loc, 3, index_local=i_loc)
+    assert none_d.numel() == 0 and none_a.numel() == 0
+    # ... and only ONE rank has valid distances: every rank gets that rank's rays
+    lone = np.where(rank == world - 1, d_tie[i_loc], np.nan)
+    lone_d, lone_a = parallel.allgather_topk(lone, a_loc, 2, index_local=i_loc)
     if rank == 0:
-        np.savez(os.path.join(out_dir, f'{mode}.npz'), H=Ht.numpy().reshape(int(shape[0]), int(shape[1])), lo=lo, hi=hi,
+        np.savez(os.path.join(out_dir, f'{mode}.npz'), lone_d=lone_d.numpy(), lone_a=lone_a.numpy(), H=Ht.numpy().reshape(int(shape[0]), int(shape[1])), lo=lo, hi=hi,
                  best_d=best_d.numpy(), best_a=best_a.numpy(), tie_d=tie_d.numpy(), tie_a=tie_a.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['interleave', 'block'])
-def test_two_ranks_reproduce_one(tmp_path, orc, mode):
+@pytest.mark.parametrize('world,mode', [(2, 'interleave'), (2, 'block'), (4, 'interleave'), (8, 'block'), (8, 'interleave')])
+def test_ranks_reproduce_one(tmp_path, orc, world, mode):
+    """N = 2, 4, 8 ranks (the driver's scaling run uses 1, 2, 4, 8): shards cover the fan, C1 / C2 / C3 give the
+    single-process plot range, map and selection (ties across ranks included)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import common
-    port = 29500 + (os.getpid() % 2000) + (0 if mode == 'interleave' else 1)
-    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 10 * world + (0 if mode == 'interleave' else 1)
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
     got = np.load(os.path.join(str(tmp_path), f'{mode}.npz'))
     g = common.load('c1_flat250')
     env = common.oracle_env(orc, g)
@@ -88,6 +96,18 @@ def test_two_ranks_reproduce_one(tmp_path, orc, mode):
     sel = sel[np.argsort(d_tie[sel], kind='stable')]
     assert len(sel) == 11
     assert np.array_equal(got['tie_d'], d_tie[sel]) and np.array_equal(got['tie_a'], a_tie[sel])
+    # only the last rank had valid distances: its rays within its 2 smallest distinct distances, in fan order
+    sys.path.insert(0, ROOT)
+    import rt2d_loader
+    rt2d_loader.load()
+    from ray_tracer_amd import parallel
+    i_last = parallel.shard_angles(a_tie, world - 1, world, mode)[1]
+    d_last = d_tie[i_last]
+    kth = np.unique(d_last[~np.isnan(d_last)])[:2][-1]
+    pick = i_last[d_last <= kth]
+    pick = np.sort(pick)
+    pick = pick[np.argsort(d_tie[pick], kind='stable')]
+    assert np.array_equal(got['lone_d'], d_tie[pick]) and np.array_equal(got['lone_a'], a_tie[pick])
 
 
 def test_shard_angles_cover_the_fan():
