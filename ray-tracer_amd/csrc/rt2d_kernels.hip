@@ -49,6 +49,10 @@ struct rt2d_env_s {
     bool ceil_is_const; // the surface table is one constant (slopes 0, equal values) ...
     double ceil_const;  // ... this one
     std::vector<double> host_blob;
+    // per frequency: -alpha(f, z) / 1000 as ONE polynomial per depth piece (alpha_table_for), built on first use
+    struct AlphaTab { double* dev = nullptr; int32_t n_pieces = 0; bool ok = false; double max_rel_err = 0.0; };
+    std::map<uint64_t, AlphaTab> alpha;
+    std::mutex alpha_mu;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -2055,6 +2059,226 @@ __global__ void __launch_bounds__(512, FAST ? 3 : LOSS ? 4 : 2) rt2d_gain_heatma
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The one pass again, for the launch that ONLY bins (the big pass of rt2d_gain_heatmap_rest: no gain leaves the kernel), by
+// instruction count (238 vector instructions per wave-point for ~40 flop of algorithm).
+//  * -alpha(f, z) / 1000 of this launch's frequency comes from ONE polynomial of degree 7 per depth piece (AlphaDesc:
+//    record = [lo, hi, c0 .. c7] about d = z - lo, same pieces and same O(1) guess as the absorption table), fitted on the
+//    host from the exact form at 8 Chebyshev nodes per piece and VERIFIED ON THE DEVICE against the exact form
+//    (rt2d_alpha_verify_kernel: 256 depths per piece, worst relative difference <= 1e-14, else the exact kernel runs):
+//    5 LDS reads and 7 FMAs instead of a 19-double record, 6 quadratics, two quotients and the /1000.
+//  * the common step -- every live ray of the wave has its depth in the guessed piece, no rebound loss due, and every
+//    binned ray enters a column further on with no row to remember -- is a straight line under ONE wave vote; a step
+//    that is not common runs the general code of the existing kernel (RayBinner::point, the exact alpha, the losses).
+//  * trajectory addresses are a scalar tile base + lane: no per-point vector address arithmetic; points are loaded
+//    ONEPASS_AHEAD steps ahead, unconditionally, from rows clamped into the wave's longest ray.
+// Lanes past their ray's end compute on whatever the tile holds there (inside the allocation: a tile has room for its
+// longest ray in every column); nothing of it reaches S of a live ray, the binner or the vote.
+#define ALPHA_DEG 7
+#define ALPHA_REC (ALPHA_DEG + 3)
+struct AlphaDesc { const double* tab; int32_t n_pieces; int32_t pad; double x0, inv_h; };
+
+__global__ void __launch_bounds__(64) rt2d_alpha_verify_kernel(DevEnv env, const double* blob, AlphaDesc ad, double freq,
+                                                               unsigned long long* worst) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const double* rec = ad.tab + (size_t)j * ALPHA_REC;
+    const double lo = rec[0], hi = rec[1];
+    const double f = freq / 1000, ff = f * f;
+    double err = 0.0;
+    for (int q = 0; q < 4; ++q) {
+        const int k = q * 64 + lane;                                      // 0 .. 255
+        double z = lo + (hi - lo) * ((double)k / 255.0);
+        if (k == 255 || !(z < hi)) z = nextafter(hi, -INFINITY);             // just inside
+        if (!(z >= lo)) z = lo;
+        // the piece the lean kernel would use for this depth must be this one
+        double g = (z - ad.x0) * ad.inv_h;
+        int jj = (int)fmin(fmax(g, 0.0), (double)(ad.n_pieces - 1));
+        if (jj != j) {
+            const double* r2 = ad.tab + (size_t)jj * ALPHA_REC;
+            if (z >= r2[0] && z < r2[1]) err = INFINITY;                  // two pieces claim the depth: never
+            continue;                                                     // (a wrong guess: the kernel takes its general step)
+        }
+        double r19[20];
+        rt2d_lookup<19>(blob + env.gain_off, env.absorb, z, r19);
+        const double want = rt2d_div_1000(-1 * rt2d_alpha(r19, z - r19[0], ff));
+        const double d = z - lo;
+        double pz = rec[2 + ALPHA_DEG];
+#pragma unroll
+        for (int m = ALPHA_DEG - 1; m >= 0; --m) pz = fma(pz, d, rec[2 + m]);
+        const double e = fabs(pz - want) / fabs(want);
+        err = (e > err || e != e) ? (e != e ? INFINITY : e) : err;
+    }
+    for (int off = 32; off > 0; off >>= 1) err = fmax(err, __shfl_xor(err, off));
+    if (lane == 0) atomicMax(worst, (unsigned long long)__double_as_longlong(err));     // non-negative doubles order as integers
+}
+
+#ifndef ONEPASS_AHEAD
+#define ONEPASS_AHEAD 4     // points in flight per lane (1 M rays: 8.3 / 7.0 / 6.6 / 8.0 ms with 1 / 2 / 4 / 6: HBM latency, then code size)
+#endif
+// what a step computes before the wave votes (one copy per unrolled common step, one in the general block)
+#define ONEPASS_HEAD(X_, Z_)                                                                                                        \
+        const double x = (X_), z = (Z_);                                                                                           \
+        const bool live = s < np;                                                                                                  \
+        /* -alpha / 1000 at the START of the segment (ray.py:346) from the guessed piece */                                        \
+        int j = (int)((zp - ad.x0) * ad.inv_h);                            /* saturating conversion, NaN -> 0 */                  \
+        j = min(max(j, 0), ad.n_pieces - 1);                                                                                       \
+        const double* rec = s_tab + j * ALPHA_REC;                                                                                 \
+        const double lo = rec[0], hi = rec[1];                                                                                     \
+        const double c0 = rec[2], c1 = rec[3], c2 = rec[4], c3 = rec[5], c4 = rec[6], c5 = rec[7], c6 = rec[8], c7 = rec[9];       \
+        const bool piece_ok = (zp >= lo) & (zp < hi);                                                                              \
+        const double d = zp - lo;                                                                                                  \
+        double pa = fma(c7, d, c6);                                                                                                \
+        pa = fma(pa, d, c5); pa = fma(pa, d, c4); pa = fma(pa, d, c3); pa = fma(pa, d, c2); pa = fma(pa, d, c1); pa = fma(pa, d, c0); \
+        const double ddx = x - xp, ddz = z - zp;                                                                                   \
+        const double dL = rt2d_sqrt_fast(fma(ddx, ddx, ddz * ddz));                                                                \
+        /* rebound losses that start with this point (ray.py:350-362): rare, and no reason to leave the common step */             \
+        if (rt2d_any(live & (s >= next_reb_at))) {                                                                                 \
+            const GainHeatArgs* cold = (const GainHeatArgs*)__builtin_amdgcn_kernarg_segment_ptr();                                \
+            asm volatile("" : "+s"(cold));                                                                                         \
+            if (live) {                                                                                                            \
+                const GainArgs& ca = cold->g;                                                                                      \
+                while (s >= next_reb_at) {                                                                                         \
+                    A += ca.loss[(int64_t)next_reb * ca.n + r];                                                                    \
+                    ++next_reb;                                                                                                    \
+                    next_reb_at = (next_reb < nreb) ? ca.reb_step[(int64_t)next_reb * ca.n + r] + 1 : 0x7fffffff;                  \
+                }                                                                                                                  \
+            }                                                                                                                      \
+        }                                                                                                                          \
+        const double Sn = fma(pa, dL, S);                                  /* ray.py:346-347 */                                   \
+        /* the cell of the new point, and what the binner (RayBinner::point) would do with it */                                   \
+        int ix, iz;                                                                                                                \
+        const bool in_map = rt2d_cell_i32(geo, x, z, ix, iz) & ((unsigned)ix < (unsigned)nx) & ((unsigned)iz < (unsigned)nz);      \
+        const bool newcol = ix != binner.cur_ix;                                                                                   \
+        const bool newrow = !newcol & (iz != binner.cur_iz);                                                                       \
+        const int k_old = binner.cur_iz & 7;                                                                                       \
+        const int lo_n = min(binner.col_lo, iz), hi_n = max(binner.col_hi, iz);                                                    \
+        /* common for a binned ray: inside the map, column not decreasing, the cell it leaves (if it leaves one) was not           \
+           deposited before in this column (its slot bit is clear: nothing to take the difference to), the plain form of the       \
+           value applies, and the rows of the column still fit the eight slots */                                                  \
+        const bool easy = in_map & (ix >= binner.cur_ix) & !((newcol | newrow) & (((binner.occ >> k_old) & 1u) != 0u))             \
+                          & (fabs(binner.cur_g) < 3000.0) & (newcol | (hi_n - lo_n < 8));                                          \
+        const bool common = piece_ok & (!binner.ok | easy);                                                                        \
+        const bool all_common = __builtin_amdgcn_ballot_w64(live & !common) == 0ull;
+
+#ifdef ONEPASS_WPE
+__attribute__((amdgpu_waves_per_eu(ONEPASS_WPE, ONEPASS_WPE)))
+#endif
+__global__ void __launch_bounds__(256) rt2d_onepass_kernel(const GainHeatArgs b, const AlphaDesc ad) {
+    const GainArgs& a = b.g;
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];         // [n_pieces][ALPHA_REC], then 8 x 64 slots per wave
+    const int tab_doubles = ad.n_pieces * ALPHA_REC;
+    for (int i = threadIdx.x; i < tab_doubles; i += blockDim.x) s_tab[i] = ad.tab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t r_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool has = r_raw < a.n;
+    const int64_t r = has ? r_raw : a.n - 1;
+    const bool binme = has && ((b.ray_mask ? b.ray_mask[r] : (uint8_t)1) & 1) != 0;
+    const int np = binme ? rt2d_stored_pts(a.n_pts, a.tile_off, r) : 0;
+    int np_max = np;
+    for (int off = 32; off > 0; off >>= 1) np_max = max(np_max, __shfl_xor(np_max, off));
+    np_max = __builtin_amdgcn_readfirstlane(np_max);
+    if (np_max == 0) return;
+    // the wave's tile: scalar base, lane offset
+    const int64_t tile = (int64_t)__builtin_amdgcn_readfirstlane((int)(r_raw >> 6));
+    const int64_t t0 = a.tile_off[tile];
+    const double* __restrict__ Xs = a.X + t0;
+    const double* __restrict__ Zs = a.Z + t0;
+    const unsigned ulane = (unsigned)lane;
+    double* const H = b.bin.H;
+    double S = 0.0, A = 0.0;
+    const int nreb = binme ? min(a.n_rebounds[r], a.rebound_cap) : 0;
+    int next_reb = 0;
+    int next_reb_at = (nreb > 0) ? a.reb_step[r] + 1 : 0x7fffffff;         // first point index that carries the loss
+    double xp = Xs[ulane], zp = Zs[ulane];
+    RayBinner binner;
+    binner.start(b.bin, binme && np > 0, s_tab + tab_doubles + (threadIdx.x >> 6) * (8 * RT2D_WAVE) + lane, xp, zp, 0.0);
+    const HeatGeom& geo = b.bin.geo;
+    const int nx = b.bin.nx, nz = b.bin.nz;
+    const double sign = b.bin.sign;
+    // the queue of points in flight: at the top of the outer loop xq[k] is row s + k (rows clamped into the longest ray)
+    double xq[ONEPASS_AHEAD], zq[ONEPASS_AHEAD];
+#pragma unroll
+    for (int u = 0; u < ONEPASS_AHEAD; ++u) {
+        const int sn = min(1 + u, np_max - 1);
+        xq[u] = (Xs + (size_t)sn * RT2D_WAVE)[ulane]; zq[u] = (Zs + (size_t)sn * RT2D_WAVE)[ulane];
+    }
+    int s = 1;                                                             // wave-uniform
+    while (s < np_max) {
+        bool general = false;
+#pragma unroll
+        for (int u = 0; u < ONEPASS_AHEAD; ++u) {
+            if (s >= np_max) break;
+            ONEPASS_HEAD(xq[u], zq[u])
+            if (!all_common) {
+                // not a common step: bring the queue back into order (slots 0 .. u-1 already hold rows s + AHEAD - u ...) and
+                // let the one general block below take this point
+                double tx[ONEPASS_AHEAD], tz[ONEPASS_AHEAD];
+#pragma unroll
+                for (int k = 0; k < ONEPASS_AHEAD; ++k) { tx[k] = xq[(k + u) % ONEPASS_AHEAD]; tz[k] = zq[(k + u) % ONEPASS_AHEAD]; }
+#pragma unroll
+                for (int k = 0; k < ONEPASS_AHEAD; ++k) { xq[k] = tx[k]; zq[k] = tz[k]; }
+                general = true;
+                break;
+            }
+            {
+                const int sn = min(s + ONEPASS_AHEAD, np_max - 1);
+                xq[u] = (Xs + (size_t)sn * RT2D_WAVE)[ulane]; zq[u] = (Zs + (size_t)sn * RT2D_WAVE)[ulane];
+            }
+            S = Sn;
+            const bool binning = live & binner.ok;
+            const bool leaving = binning & (newcol | newrow);
+            const double v = sign * rt2d_heat_val_plain(binner.cur_g);                        // ray.py:317, simulation.py:129
+            rt2d_deposit_full(H, leaving, binner.cur_ix * nz + binner.cur_iz, v, lane);
+            if (binning & newrow) { binner.slot[k_old * RT2D_WAVE] = v; binner.occ |= 1u << k_old; binner.col_lo = lo_n; binner.col_hi = hi_n; }
+            if (binning & newcol) { binner.occ = 0u; binner.col_lo = iz; binner.col_hi = iz; }
+            if (binning) { binner.cur_ix = ix; binner.cur_iz = iz; binner.cur_g = Sn + A; }
+            xp = x; zp = z;
+            ++s;
+        }
+        if (general) {
+            // general step (ONE copy): whatever the existing kernel does for this point -- the exact alpha where the guess was
+            // wrong, RayBinner's remembered rows, violations.  Everything it needs of the launch arguments is read HERE, through
+            // the kernel-argument pointer laundered by an empty asm: loop-invariant loads of a cold path would otherwise be
+            // hoisted in front of the loop and hold scalar registers that the common step's constants need.
+            ONEPASS_HEAD(xq[0], zq[0])
+            (void)Sn; (void)all_common; (void)lo_n; (void)hi_n; (void)k_old; (void)newrow;
+#pragma unroll
+            for (int k = 0; k + 1 < ONEPASS_AHEAD; ++k) { xq[k] = xq[k + 1]; zq[k] = zq[k + 1]; }
+            {
+                const int sn = min(s + ONEPASS_AHEAD, np_max - 1);
+                xq[ONEPASS_AHEAD - 1] = (Xs + (size_t)sn * RT2D_WAVE)[ulane]; zq[ONEPASS_AHEAD - 1] = (Zs + (size_t)sn * RT2D_WAVE)[ulane];
+            }
+            const GainHeatArgs* cold = (const GainHeatArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(cold));
+            if (live) {
+                const GainArgs& ca = cold->g;
+                double pe = pa;
+                if (!piece_ok) {
+                    double r19[20];
+                    rt2d_lookup<19>(ca.blob + ca.env.gain_off, ca.env.absorb, zp, r19);
+                    const double fc = cold->freq / 1000;
+                    const double al = -rt2d_alpha_fast(r19, zp - r19[0], fc * fc);
+                    const double q = al * 0.001;
+                    pe = fma(fma(-q, 1000.0, al), 0.001, q);
+                }
+                S = fma(pe, dL, S);
+            }
+            binner.point<true>(cold->bin, x, z, S + A, lane, live);
+            xp = x; zp = z;
+            ++s;
+        }
+    }
+    {
+        const GainHeatArgs* cold = (const GainHeatArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(cold));
+        binner.finish<true>(cold->bin, lane);
+    }
+    if (!binme || np == 0) return;
+    if (b.irregular) b.irregular[r] = binner.violated ? 1 : 0;
+    if (binner.violated && b.n_violations) atomicAdd(b.n_violations, 1ull);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // distance to target from stored trajectories (ray.py:282-287)
 __global__ void __launch_bounds__(256) rt2d_dist_kernel(const double* X, const double* Z, const int64_t* tile_off,
                                                         const int32_t* n_pts, int64_t n, double tx, double tz, double* dist) {
@@ -2667,6 +2891,7 @@ int32_t rt2d_env_create(const Rt2dEnvDesc* d, rt2d_env_t* env_out) {
 int32_t rt2d_env_destroy(rt2d_env_t env) {
     if (!env) return 0;
     if (env->blob) (void)hipFree(env->blob);
+    for (auto& kv : env->alpha) if (kv.second.dev) (void)hipFree(kv.second.dev);
     delete env;
     return 0;
 }
@@ -3069,6 +3294,87 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
 
 
 extern "C++" {
+// -alpha(f, z) / 1000 of ONE frequency as a polynomial of degree ALPHA_DEG per depth piece of the absorption table (see
+// rt2d_onepass_kernel).  Host: the exact form (model_absorption.py:37-44 on the six quadratics of the piece, the very
+// arithmetic of rt2d_alpha: only + * /) at the Chebyshev nodes of the piece, interpolated in long double.  The end pieces
+// reach to the environment's rectangle (every stored point but a source outside it lies inside).  Device: the finished
+// table is checked against the exact form (rt2d_alpha_verify_kernel); a table that misses 1e-14 relative anywhere is kept
+// as "not ok" and the caller uses the exact kernel.  One table per (environment, frequency), made once (one small
+// allocation, one copy, one launch, one 8-byte read back) and kept until the environment is destroyed.
+static int32_t alpha_table_for(rt2d_env_t env, double freq, AlphaDesc* out, bool* ok) {
+    *ok = false;
+    const DevTable& ab = env->dev.absorb;
+    if (!ab.uniform || ab.stride != 19 || ab.n_pieces < 1) return 0;
+    uint64_t key; memcpy(&key, &freq, sizeof key);
+    std::lock_guard<std::mutex> lock(env->alpha_mu);
+    auto it = env->alpha.find(key);
+    if (it == env->alpha.end()) {
+        if (env->alpha.size() >= 4096) return 0;                          // (a sweep over thousands of frequencies: exact kernel)
+        const int n = ab.n_pieces, D = ALPHA_DEG, N = D + 1;
+        const double* base = env->host_blob.data() + env->dev.gain_off + ab.off;
+        const double f = freq / 1000, ff = f * f;
+        std::vector<double> tab((size_t)n * ALPHA_REC);
+        for (int j = 0; j < n; ++j) {
+            const double* rec = base + (size_t)j * 19;
+            double lo = rec[0], hi = rec[19];
+            if (j == 0) lo = fmin(lo, env->dev.range_min[1]) - 1.0;
+            if (j == n - 1) hi = fmax(hi, env->dev.range_max[1]) + 1.0;
+            long double V[N][N + 1];
+            for (int k = 0; k < N; ++k) {
+                const long double u = (1.0L + cosl(3.14159265358979323846264338327950288L * (k + 0.5L) / N)) / 2;
+                const double z = (double)((long double)lo + ((long double)hi - lo) * u);
+                const double d = z - rec[0];
+                auto quad = [&](int q) { return (rec[1 + 3 * q] * d + rec[2 + 3 * q]) * d + rec[3 + 3 * q]; };
+                const double f1 = quad(0), f2 = quad(1), A2 = quad(2), E1 = quad(3), E2 = quad(4), E3 = quad(5);
+                const double alpha_1 = 0.106 * (f1 * ff) / (f1 * f1 + ff);
+                const double alpha_2 = A2 * (f2 * ff) / (f2 * f2 + ff);
+                const double alpha_3 = 0.00049 * ff;
+                const double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
+                const long double uu = ((long double)z - lo) / ((long double)hi - lo);
+                long double pw = 1;
+                for (int m = 0; m < N; ++m) { V[k][m] = pw; pw *= uu; }
+                V[k][N] = -(long double)alpha / 1000;
+            }
+            for (int c = 0; c < N; ++c) {                                  // Gauss-Jordan with partial pivoting
+                int piv = c;
+                for (int k = c + 1; k < N; ++k) if (fabsl(V[k][c]) > fabsl(V[piv][c])) piv = k;
+                if (piv != c) for (int m = 0; m <= N; ++m) std::swap(V[c][m], V[piv][m]);
+                if (V[c][c] == 0) return 0;
+                for (int k = 0; k < N; ++k) {
+                    if (k == c) continue;
+                    const long double g = V[k][c] / V[c][c];
+                    for (int m = c; m <= N; ++m) V[k][m] -= g * V[c][m];
+                }
+            }
+            double* o = &tab[(size_t)j * ALPHA_REC];
+            o[0] = lo; o[1] = hi;
+            long double scale = 1;
+            for (int m = 0; m < N; ++m) { o[2 + m] = (double)(V[m][N] / V[m][m] / scale); scale *= ((long double)hi - lo); }
+        }
+        rt2d_env_s::AlphaTab t;
+        t.n_pieces = n;
+        unsigned long long* worst = nullptr;
+        HIP_OK(hipMalloc(&t.dev, tab.size() * sizeof(double) + 8));
+        worst = (unsigned long long*)(t.dev + tab.size());
+        unsigned long long zero = 0, got = ~0ull;
+        hipError_t e1 = hipMemcpy(t.dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t e2 = hipMemcpy(worst, &zero, 8, hipMemcpyHostToDevice);
+        AlphaDesc ad; ad.tab = t.dev; ad.n_pieces = n; ad.pad = 0; ad.x0 = ab.x0; ad.inv_h = ab.inv_h;
+        if (e1 == hipSuccess && e2 == hipSuccess) {
+            hipLaunchKernelGGL(rt2d_alpha_verify_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)0, env->dev, env->blob, ad, freq, worst);
+            if (hipGetLastError() == hipSuccess && hipMemcpy(&got, worst, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                memcpy(&t.max_rel_err, &got, 8);
+                t.ok = t.max_rel_err <= 1e-14;
+            }
+        }
+        it = env->alpha.emplace(key, t).first;
+    }
+    const rt2d_env_s::AlphaTab& t = it->second;
+    out->tab = t.dev; out->n_pieces = t.n_pieces; out->pad = 0; out->x0 = ab.x0; out->inv_h = ab.inv_h;
+    *ok = t.ok;
+    return 0;
+}
+
 static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                           const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                           const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,
@@ -3109,6 +3415,25 @@ static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* 
         a.loss = loss_ws;
         kern = rt2d_gain_heatmap_kernel<true>;
         if (!G && !G_end && !b.exact) kern = rt2d_gain_heatmap_kernel<true, true>;
+        // ... and when nothing but the map is asked of every ray of a whole fan: the lean form (rt2d_onepass_kernel), if the
+        // alpha table of this frequency passes its check on the device
+        static const int lean_env = getenv("RT2D_GH_LEAN") ? atoi(getenv("RT2D_GH_LEAN")) : 1;
+        if (lean_env && !G && !G_end && !b.exact && !ray_list && !irregular && b.bin.dbg == 0) {
+            AlphaDesc ad; bool ok = false;
+            int32_t rc = alpha_table_for(env, freq, &ad, &ok);
+            if (rc) return rc;
+            if (ok) {
+                const int lean_block = 256;
+                const size_t lean_lds = ((size_t)ad.n_pieces * ALPHA_REC + (size_t)(lean_block / RT2D_WAVE) * 8 * RT2D_WAVE) * sizeof(double);
+                if (lean_lds <= RT2D_LDS_BUDGET) {
+                    ALLOW_LDS(rt2d_onepass_kernel, lean_lds);
+                    hipLaunchKernelGGL(rt2d_onepass_kernel, dim3((unsigned)((n + lean_block - 1) / lean_block)), dim3(lean_block), lean_lds,
+                                       (hipStream_t)stream, b, ad);
+                    HIP_OK(hipGetLastError());
+                    return 0;
+                }
+            }
+        }
     }
     ALLOW_LDS(kern, lds);
     if (n_launch > 0)

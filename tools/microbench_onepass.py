@@ -30,3 +30,14 @@ e0.record()
 for _ in range(3): run()
 e1.record(); torch.cuda.synchronize()
 print(f"dbg={os.environ.get('RT2D_FUSE_DBG','0')} block={os.environ.get('RT2D_GH_BLOCK','auto')} n={n}: {e0.elapsed_time(e1)/3:.2f} ms (incl. 0.25 ms rebound-loss kernel), violations {int(viol.item())}")
+# one clean map of this form (RT2D_GH_LEAN = 1: rt2d_onepass_kernel, 0: rt2d_gain_heatmap_kernel<true, true>) for comparison
+H.zero_(); run(); torch.cuda.synchronize()
+tag = os.environ.get('RT2D_GH_LEAN', '1')
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+np.save(os.path.join(ROOT, 'gpurun_out', f'onepass_H_lean{tag}.npy'), H.cpu().numpy())
+other = os.path.join(ROOT, 'gpurun_out', f'onepass_H_lean{"0" if tag != "0" else "1"}.npy')
+if os.path.exists(other):
+    Ho, Hn = np.load(other), H.cpu().numpy()
+    both = (Ho != 0) & np.isfinite(Ho)
+    print(f'maps lean vs exact: same occupancy {np.array_equal(Ho == 0, Hn == 0)}, worst relative difference '
+          f'{(np.abs(Hn - Ho)[both] / np.abs(Ho[both])).max():.3e}, sum {Hn.sum():.9f} vs {Ho.sum():.9f}')
