@@ -126,6 +126,34 @@ __device__ __forceinline__ double rt2d_exp2(double t) {
     return ldexp(p, (int)n);
 }
 
+// The same polynomial with every Horner step written as a three-address v_fma_f64: inside a loop the compiler keeps the
+// thirteen coefficients in vector registers (no fp64 literals in VOP3 on gfx9) and then forms each step as a copy of the
+// coefficient plus a two-address v_fmac_f64 -- twelve copies per evaluation.  Same operations, same roundings.
+__device__ __forceinline__ double rt2d_fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double rt2d_exp2_3addr(double t) {
+    const double n = rint(t);
+    const double f = t - n;
+    double p = 0x1.816193166d0f9p-40;
+    p = rt2d_fma3(p, f, 0x1.c3bd650fc2986p-36);
+    p = rt2d_fma3(p, f, 0x1.e8cac7351bb25p-32);
+    p = rt2d_fma3(p, f, 0x1.e4cf5158b8ecap-28);
+    p = rt2d_fma3(p, f, 0x1.b5253d395e7c4p-24);
+    p = rt2d_fma3(p, f, 0x1.62c0223a5c824p-20);
+    p = rt2d_fma3(p, f, 0x1.ffcbfc588b0c7p-17);
+    p = rt2d_fma3(p, f, 0x1.430912f86c787p-13);
+    p = rt2d_fma3(p, f, 0x1.5d87fe78a6731p-10);
+    p = rt2d_fma3(p, f, 0x1.3b2ab6fba4e77p-7);
+    p = rt2d_fma3(p, f, 0x1.c6b08d704a0c0p-5);
+    p = rt2d_fma3(p, f, 0x1.ebfbdff82c58fp-3);
+    p = rt2d_fma3(p, f, 0x1.62e42fefa39efp-1);
+    p = fma(p, f, 1.0);
+    return ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ bool rt2d_heat_val_is_plain(double g) { return g > -3000.0 && g < 3000.0; }
 __device__ __forceinline__ double rt2d_heat_val_plain(double g) { return rt2d_exp2(g * -0.033219280948873623); }   // -log2(10)/100
 __device__ __forceinline__ double rt2d_heat_val_pows(double g) {
@@ -2066,9 +2094,11 @@ __global__ void __launch_bounds__(512, FAST ? 3 : LOSS ? 4 : 2) rt2d_gain_heatma
 //    host from the exact form at 8 Chebyshev nodes per piece and VERIFIED ON THE DEVICE against the exact form
 //    (rt2d_alpha_verify_kernel: 256 depths per piece, worst relative difference <= 1e-14, else the exact kernel runs):
 //    5 LDS reads and 7 FMAs instead of a 19-double record, 6 quadratics, two quotients and the /1000.
-//  * the common step -- every live ray of the wave has its depth in the guessed piece, no rebound loss due, and every
-//    binned ray enters a column further on with no row to remember -- is a straight line under ONE wave vote; a step
-//    that is not common runs the general code of the existing kernel (RayBinner::point, the exact alpha, the losses).
+//  * the common step -- every live ray of the wave has its depth in the guessed piece, and every binned ray stays in its
+//    cell or leaves it (new column or new row: half of the C2 fan is steep rays that change ROW every step) for a cell
+//    inside the map without a remembered deposit to take the difference to -- is a straight line under ONE wave vote;
+//    a step that is not common runs the general code of the existing kernel (RayBinner::point, the exact alpha) in ONE
+//    block outside the unrolled steps.  Rebound losses are added where they fall due without leaving the common step.
 //  * trajectory addresses are a scalar tile base + lane: no per-point vector address arithmetic; points are loaded
 //    ONEPASS_AHEAD steps ahead, unconditionally, from rows clamped into the wave's longest ray.
 // Lanes past their ray's end compute on whatever the tile holds there (inside the allocation: a tile has room for its
@@ -2111,8 +2141,17 @@ __global__ void __launch_bounds__(64) rt2d_alpha_verify_kernel(DevEnv env, const
     if (lane == 0) atomicMax(worst, (unsigned long long)__double_as_longlong(err));     // non-negative doubles order as integers
 }
 
+// Points in flight per lane and waves per SIMD (1 M-ray C2 fan, kernel + 0.25 ms of rebound losses): at 139 registers
+// (3 waves per SIMD) 6.24 / 6.12 / 6.22 / 6.28 ms with 3 / 4 / 6 / 8 points in flight; bounded to 128 registers (4 waves
+// per SIMD) 5.70 / 5.65 / 6.51 ms with 2 / 3 / 4 (the fourth spills).  Before the general block became ONE copy outside
+// the unrolled steps the same sweep read 8.3 / 7.0 / 6.6 / 8.0 ms with 1 / 2 / 4 / 6: first HBM latency, then code size.
+// With the three-address exp2 (12 copies fewer per step, 174 vector instructions per wave-point by SQ_INSTS_VALU against
+// 238 for rt2d_gain_heatmap_kernel<true, true>): 5.57 ms with 2 points in flight, 5.9 with 3 (two registers spilled).
 #ifndef ONEPASS_AHEAD
-#define ONEPASS_AHEAD 4     // points in flight per lane (1 M rays: 8.3 / 7.0 / 6.6 / 8.0 ms with 1 / 2 / 4 / 6: HBM latency, then code size)
+#define ONEPASS_AHEAD 2
+#endif
+#ifndef ONEPASS_WPE
+#define ONEPASS_WPE 4
 #endif
 // what a step computes before the wave votes (one copy per unrolled common step, one in the general block)
 #define ONEPASS_HEAD(X_, Z_)                                                                                                        \
@@ -2159,9 +2198,7 @@ __global__ void __launch_bounds__(64) rt2d_alpha_verify_kernel(DevEnv env, const
         const bool common = piece_ok & (!binner.ok | easy);                                                                        \
         const bool all_common = __builtin_amdgcn_ballot_w64(live & !common) == 0ull;
 
-#ifdef ONEPASS_WPE
 __attribute__((amdgpu_waves_per_eu(ONEPASS_WPE, ONEPASS_WPE)))
-#endif
 __global__ void __launch_bounds__(256) rt2d_onepass_kernel(const GainHeatArgs b, const AlphaDesc ad) {
     const GainArgs& a = b.g;
     extern __shared__ __attribute__((aligned(16))) double s_tab[];         // [n_pieces][ALPHA_REC], then 8 x 64 slots per wave
@@ -2227,7 +2264,7 @@ __global__ void __launch_bounds__(256) rt2d_onepass_kernel(const GainHeatArgs b,
             S = Sn;
             const bool binning = live & binner.ok;
             const bool leaving = binning & (newcol | newrow);
-            const double v = sign * rt2d_heat_val_plain(binner.cur_g);                        // ray.py:317, simulation.py:129
+            const double v = sign * rt2d_exp2_3addr(binner.cur_g * -0.033219280948873623);    // ray.py:317, simulation.py:129; -log2(10)/100
             rt2d_deposit_full(H, leaving, binner.cur_ix * nz + binner.cur_iz, v, lane);
             if (binning & newrow) { binner.slot[k_old * RT2D_WAVE] = v; binner.occ |= 1u << k_old; binner.col_lo = lo_n; binner.col_hi = hi_n; }
             if (binning & newcol) { binner.occ = 0u; binner.col_lo = iz; binner.col_hi = iz; }
