@@ -269,6 +269,15 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
                                const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
                                int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream);
 
+/* Diagnostic of the binning-only pass of rt2d_gain_heatmap / rt2d_gain_heatmap_rest (reference: the absorption of
+ * ray.py:346 = model_absorption.py:19-46 at ONE frequency; no counterpart of the table itself).  When a launch stores no
+ * gain, -alpha(freq, z) / 1000 is read from one polynomial of degree 7 per depth piece of the absorption table, fitted on
+ * the host and CHECKED ON THE DEVICE against the exact form at 256 depths per piece; the table is only used when the worst
+ * relative difference is <= 1e-14 (else the exact form runs).  This call builds the table of `freq` if it is not there yet
+ * (one small device allocation, kept until rt2d_env_destroy) and reports that worst relative difference and whether the
+ * table is in use (1) or not (0).  RT2D_GH_LEAN=0 in the environment switches the table and its kernel off altogether. */
+int32_t rt2d_alpha_table_error(rt2d_env_t env, double freq, double* max_rel_err, int32_t* in_use);
+
 /* The ray_mask, rest_list and g_slot arguments of rt2d_gain_heatmap_rest, made on the device from a cast's per-ray results
  * (no reference counterpart: RayFan.fused_mask, which it restates, needs the host to wait for the cast): m[r] = 1 / 2 / 0 as
  * described there for the rays with status 0 (and ray_mask != 0 when one is given); the rays of value 2 are appended to

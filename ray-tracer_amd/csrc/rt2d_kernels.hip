@@ -3480,6 +3480,20 @@ static int32_t gain_heatmap_impl(rt2d_env_t env, const double* X, const double* 
 }
 }  // extern "C++"
 
+int32_t rt2d_alpha_table_error(rt2d_env_t env, double freq, double* max_rel_err, int32_t* in_use) {
+    if (!env || !max_rel_err || !in_use) return fail("rt2d_alpha_table_error: null argument");
+    if (!(freq > 0)) return fail("rt2d_alpha_table_error: freq must be positive");
+    AlphaDesc ad; bool ok = false;
+    int32_t rc = alpha_table_for(env, freq, &ad, &ok);
+    if (rc) return rc;
+    uint64_t key; memcpy(&key, &freq, sizeof key);
+    std::lock_guard<std::mutex> lock(env->alpha_mu);
+    auto it = env->alpha.find(key);
+    *max_rel_err = it == env->alpha.end() ? INFINITY : it->second.max_rel_err;
+    *in_use = ok ? 1 : 0;
+    return 0;
+}
+
 int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                           const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                           const int32_t* res, const int32_t* shape, double* H, double* G, double* G_end,

@@ -84,3 +84,47 @@ def test_one_pass_map_queued_without_waiting_for_the_cast(rt, monkeypatch):
         assert Hx.shape == Ha.shape and np.array_equal(Hx == 0, Ha == 0)
         both = np.isfinite(Ha) & (Ha != 0)
         assert (np.abs(Hx - Ha)[both] / np.abs(Ha[both])).max() < 1e-12
+
+
+@pytest.mark.parametrize('name', ['c2_fan999', 'c3_bathy999', 't3_default10'])
+def test_alpha_table_is_verified_on_the_device(rt, name):
+    """The binning-only pass reads -alpha(f, z) / 1000 from one degree-7 polynomial per depth piece (rt2d_onepass_kernel);
+    the library checks every table on the device against the exact form (model_absorption.py:19-46 on the six interpolated
+    factors) and only uses it when the worst relative difference is <= 1e-14: rt2d_alpha_table_error reports both."""
+    import ctypes as C
+    g = common.load(name)
+    env = common.product_env(rt, g)
+    L = rt._lib.lib()
+    h = env.device_handle(0)
+    for freq in (1., 37.5, 1000., 12345.6, 20000.):
+        err, used = C.c_double(-1.), C.c_int32(-1)
+        rt._lib.check(L.rt2d_alpha_table_error(h, float(freq), C.byref(err), C.byref(used)))
+        print(f'{name}: alpha table at {freq} Hz: worst relative difference to the exact form {err.value:.2e}, in use {used.value}')
+        assert 0 <= err.value <= 1e-14 and used.value == 1
+    with pytest.raises(rt._lib.Rt2dError):
+        rt._lib.check(L.rt2d_alpha_table_error(h, -1., C.byref(err), C.byref(used)))
+
+
+def test_lean_one_pass_kernel_against_the_three_kernel_map_on_rays_that_leave_its_common_step(rt):
+    """A fan whose rays turn back on a steep wall, rebound dozens of times in shallow water and cross depths outside the
+    absorption table's interior pieces: the one-pass map (rt2d_onepass_kernel for the rays it may bin, its general block for
+    every step that is not common) against gain + tile/general binner of the same stored fan, every cell to 1e-12."""
+    import torch
+    xs = np.linspace(0., 20000., 401)
+    zs = np.where(xs < 9000., -900., -900. + (xs - 9000.) * 0.9)
+    zs = np.minimum(zs, -20.)
+    env = rt.Environment2D((xs, zs), (np.array([0., 20000.]), np.array([0., 0.])), np.array([0., -1001.]), np.array([20000., 1.]))
+    angles = np.linspace(-0.9, 0.25, 3000)
+    for freq in (1, 3000.):
+        fan = rt.RayFan(env, np.array([0., -40.]), angles, dx_max=50., dz_max=25., n_rebounds_max=30)
+        shape = (402, 42)
+        Hs = torch.zeros(shape[0] * shape[1], dtype=torch.float64, device='cuda')
+        Hr = torch.zeros_like(Hs)
+        mask = (fan.status == 0).to(torch.uint8)
+        fan.heatmap_accumulate(Hs, (50, 25), shape, freq=freq, ray_mask=mask, stream=True)
+        assert int(fan.last_fused_violations.item()) == 0
+        fan.heatmap_accumulate(Hr, (50, 25), shape, freq=freq, ray_mask=mask, stream=False)
+        Hs, Hr = Hs.cpu().numpy(), Hr.cpu().numpy()
+        assert np.array_equal(Hs == 0, Hr == 0) and np.array_equal(np.isinf(Hs), np.isinf(Hr))
+        both = np.isfinite(Hr) & (Hr != 0)
+        assert (np.abs(Hs - Hr)[both] / np.abs(Hr[both])).max() < 1e-12
