@@ -255,12 +255,16 @@ def pmc_traffic(large):
     if stale:
         return None, f'{os.path.relpath(files[-1], ROOT)}: {stale}'
     k = prof['kernels']
-    cand = [(int(name.split('grid=')[1].split('|')[0]), v) for name, v in k.items()
-            if name.startswith('rt2d_cast_kernel<true') and v.get('hbm_bytes') is not None]
+    # the launch is told apart by its grid: the 1M-ray fan is one thread per ray; the 999-ray fan runs as waves of 4 rays (one
+    # wave per CU on 256 CUs: launch_cast2), i.e. 250 waves = 16 000 threads.  (Other blocks of this file launch the same
+    # kernel with other grids -- the 10-ray default-step fan, the refine cones -- and the profile passes skip the bathymetry
+    # fan, whose launches have the 1M-ray fan's grid and 1.44 x its points: --profile-pass.)
+    want = large if isinstance(large, int) and large > 1 else ((1 << 20) if large else 16000)
+    cand = [v for name, v in k.items() if name.startswith('rt2d_cast_kernel<true') and ', 1, false, true, 0>' in name.split('|')[0]
+            and int(name.split('grid=')[1].split('|')[0]) == want and v.get('hbm_bytes') is not None]
     if not cand:
-        return None, f'{os.path.relpath(files[-1], ROOT)} has no FETCH_SIZE / WRITE_SIZE pass of the storing cast'
-    cand.sort(key=lambda c: c[0])
-    return (cand[-1] if large else cand[0])[1]['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+        return None, f'{os.path.relpath(files[-1], ROOT)} has no FETCH_SIZE / WRITE_SIZE pass of the storing cast with grid {want}'
+    return cand[0]['hbm_bytes'], os.path.relpath(files[-1], ROOT)
 
 
 def profile_is_stale(prof):
@@ -506,6 +510,10 @@ def main():
     ap.add_argument('--large-steps', type=int, default=3)
     ap.add_argument('--default-rays', type=int, default=65536, help='rays of the default-step-size C2 fan (0 = skip the block)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--profile-pass', action='store_true',
+                    help='tools/profile_gpu.sh: skip the blocks whose launches share kernel name AND grid size with the C2 fans '
+                         '(the bathymetry fan) or only add long latency-bound launches (default step sizes, sweep + refine), '
+                         'so that per-(kernel, grid) averages of the profile are of one workload')
     ap.add_argument('--force-collectives', action='store_true',
                     help='run the two all-reduces of the step even in a group of one rank (rehearses RCCL on a 1-GPU box)')
     ap.add_argument('--dry-run', action='store_true', help='ranks print their torch.distributed environment and exit (launcher test)')
@@ -771,7 +779,7 @@ def main():
         # the same fan over a bathymetry cut (BASELINE configs 3 / 5: the floor is a table cut out of an ESRI grid;
         # the reference's data/asc file is absent, so the synthetic grid of the parity fixtures stands in)
         asc = os.path.join(ROOT, 'tests', 'golden', 'synth_bathy.asc')
-        if os.path.exists(asc):
+        if os.path.exists(asc) and not args.profile_pass:
             bmap = rt.Map.from_asc(asc)
             b0, b1 = (3.05, 41.7), (3.9, 41.75)
             length = float(bmap.cut_length(b0, b1))
@@ -805,7 +813,8 @@ def main():
             sim_e.refine(iterations=3, n_rays=5, force_refine=True)
             torch.cuda.synchronize(); t2 = time.perf_counter()
             return sim_e, t1 - t0, t2 - t1
-        eigen()
+        if not args.profile_pass:
+            eigen()
         sim_e, t_sweep, t_refine = eigen()
         cone = sim_e.last_cone_fan
         result['config5_sweep_refine'] = {
@@ -817,7 +826,7 @@ def main():
                                   'lane_utilisation': lane_utilisation(cone.n_pts),
                                   'longest_ray_points': int(cone.n_pts.max().item())}}
         del sim_e, cone
-        if args.default_rays > 0:
+        if args.default_rays > 0 and not args.profile_pass:
             result['default_resolution'] = default_resolution_block(rt, torch, env, device, args.default_rays)
     if rank == 0 and world == 1:
         # "raypower cutoff=0.5" read the other way (SURVEY trap 2): rays END when their power falls below the cutoff --

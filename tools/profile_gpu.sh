@@ -19,7 +19,7 @@ mkdir -p "$OUT"
 # in the development container): stamped into every summary by tools/summarize_profile.py
 python3 -c "import sys, json; sys.path.insert(0, '$REPO'); import rt2d_loader; rt = rt2d_loader.load(); print(json.dumps(rt._lib.build_info()))" > "$OUT/build.json"
 cd /tmp && export TMPDIR=/tmp
-BENCH="$REPO/bench.py --no-cpu $*"
+BENCH="$REPO/bench.py --no-cpu --profile-pass $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $BENCH --steps 30 --warmup 3 --large-steps 3 > "$OUT/trace.log" 2>&1
 echo "trace done"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 $BENCH --steps 3 --warmup 1 --large-steps 2 > "$OUT/fetch.log" 2>&1
