@@ -14,11 +14,28 @@ import common
 pytestmark = pytest.mark.gpu
 
 
-def test_million_ray_fan_properties(rt):
+def _bathymetry_env(rt):
+    """The environment of bench.py's large_fan_bathymetry block: Map.from_asc of the synthetic grid, a 63 km cut as a floor
+    table of 751 samples, source at -50 m (north_star's "1M-ray heat map over a bathymetry cut")."""
+    import os
+    bmap = rt.Map.from_asc(os.path.join(common.GOLD, 'synth_bathy.asc'))
+    b0, b1 = (3.05, 41.7), (3.9, 41.75)
+    length = float(bmap.cut_length(b0, b1))
+    env = rt.Environment2D(bmap.floor_table(b0, b1, npoints=751), (np.array([0., length]), np.array([0., 0.])),
+                           np.array([0., -2501.]), np.array([length, 1.]))
+    return env, np.array([0., -50.])
+
+
+@pytest.mark.parametrize('where_env', ['c2', 'bathymetry'])
+def test_million_ray_fan_properties(rt, where_env):
     import torch
-    g = common.load('c2_fan999')
-    env = common.product_env(rt, g)
+    g = common.load('c2_fan999' if where_env == 'c2' else 'c3_bathy999')
     kw = common.prop_kwargs(g)
+    if where_env == 'c2':
+        env = common.product_env(rt, g)
+    else:
+        env, src = _bathymetry_env(rt)
+        g = dict(g); g['fan_source'] = src
     n = 1 << 20
     small = np.asarray(g['fan_angles'], dtype=np.float64)
     angles = -(np.arange(n) + 1) * (0.999 / n)
@@ -37,6 +54,7 @@ def test_million_ray_fan_properties(rt):
     ok = fan.status == 0
     steps = int((fan.n_pts[ok] - 1).sum().item())
     assert steps > 8e8
+    print(f'{where_env}: {steps} ray-steps, {int((~ok).sum().item())} rays with an error status')
 
     # one shape for all maps: the whole fan's plot range
     sim = rt.Simulation2D(env, g['fan_source'])
@@ -57,6 +75,16 @@ def test_million_ray_fan_properties(rt):
     assert tol < 1e-3
     assert float((H_all - (H_even + H_odd)).abs().max().item()) <= tol
     assert torch.equal(H_all == 0, (H_even + H_odd) == 0)
+
+    # gain + binning in one pass over the stored fan (rt2d_gain_heatmap_rest: the lean kernel, its general block, the side rays)
+    H_s = torch.zeros_like(H_all)
+    fan.heatmap_accumulate(H_s, res, shape, freq=1000., ray_mask=ok8, stream=True)
+    H_3 = torch.zeros_like(H_all)
+    fan.heatmap_accumulate(H_3, res, shape, freq=1000., ray_mask=ok8, stream=False)
+    assert int(fan.last_fused_violations.item()) == 0
+    fin = torch.isfinite(H_3)
+    assert torch.equal(torch.isfinite(H_s), fin) and torch.equal(H_s == 0, H_3 == 0)
+    assert float((H_s - H_3)[fin].abs().max().item()) <= n * 2.0 ** -53 * float(H_3[fin].max().item())
 
     # fused kernel (nothing stored) on the same rays
     lean = rt.RayFan(env, g['fan_source'], angles, store=False, **kw)
