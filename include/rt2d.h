@@ -344,6 +344,22 @@ int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const do
 int32_t rt2d_heatmap_finalize_multi(const double* H, const int32_t* shape, int32_t n_maps, double cutoff,
                                     double reduction_power, double* out, double* scratch, void* stream);
 
+/* Heat map of a SMALL fan in one call: gain at `freq` (ray.py:339-362) and binning (simulation.py:120-131, functions.py:12-19)
+ * of every ray by one kernel launch -- one workgroup per ray, nothing written but the map -- followed, when `out` is given,
+ * by the normalisation of rt2d_heatmap_finalize (simulation.py:133-138).  Same map as rt2d_gain + rt2d_heatmap_accumulate
+ * (+ rt2d_heatmap_finalize) of the same stored fan to 1e-12 (the running sum of a ray is a block scan here, not
+ * np.cumsum's order, and no gain array exists).  Rays with reb->status != 0 (or ray_mask == 0 when one is given) are left
+ * out.  H: nx * nz doubles, zeroed by the caller (the call ACCUMULATES).  A workgroup holds a ray of at most 2048 stored points.
+ * max_pts: an upper bound of the stored points of any ray (the room of the layout); when it exceeds 2048 the caller must
+ * pass `overflow`, a device double that the kernel sets to 1 if a ray really is longer (the map is then INCOMPLETE and the
+ * fan must be binned with rt2d_gain + rt2d_heatmap_accumulate instead; the word is never cleared here), else the call is
+ * rejected and nothing runs.  scratch: 2 doubles (with `out`).  For fans of a few thousand rays at most: beyond,
+ * rt2d_gain_heatmap_rest and the tile kernels are the faster forms. */
+int32_t rt2d_small_fan_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                               const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, int64_t max_pts, double freq,
+                               const uint8_t* ray_mask, const int32_t* res, const int32_t* shape, double* H, int64_t* n_dropped,
+                               double cutoff, double reduction_power, double* out, double* scratch, double* overflow, void* stream);
+
 /* rt2d_heatmap_accumulate for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and same map
  * as rt2d_heatmap_accumulate called with a workspace, but the work list lives in a device array built into the library

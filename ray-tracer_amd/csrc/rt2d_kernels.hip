@@ -1379,13 +1379,11 @@ __global__ void __launch_bounds__(1024) rt2d_small_summary_kernel(const int32_t*
     __shared__ int64_t s_len[1024];
     __shared__ double s_part[16][7];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t t = wave; t < 1024; t += 16) {
-        int v = 0;
-        if (t < n_tiles) {
-            const int64_t r = t * RT2D_WAVE + lane;
-            v = (r < n) ? n_pts[r] : 0;
-            for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-        }
+    if (threadIdx.x >= n_tiles) s_len[threadIdx.x] = 0;        // (entries past the last tile: one store each, not a turn of the loop below)
+    for (int64_t t = wave; t < n_tiles; t += 16) {
+        const int64_t r = t * RT2D_WAVE + lane;
+        int v = (r < n) ? n_pts[r] : 0;
+        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
         if (lane == 0) s_len[t] = (int64_t)v * RT2D_WAVE;
     }
     __syncthreads();
@@ -2776,6 +2774,224 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Small fans (one workgroup per ray is all there is to fill the chip with): gain at one frequency AND binning of a ray in
+// ONE launch, nothing written but the map.  Replaces, for Simulation2D.heatmap() of a freshly cast small fan, the three
+// launches rt2d_gain_dg_kernel -> rt2d_gain_scan_part_kernel -> rt2d_heatmap_kernel and the gain array between them
+// (ten launches behind a 0.59 ms cast).  A thread owns a CONTIGUOUS chunk of the ray's points (at most
+// TAIL_MAXC): their dG (ray.py:346, alpha from the verified table of rt2d_onepass_kernel or the exact form), a block scan
+// for the running sum (ray.py:347; summation order differs from np.cumsum's, the map's tolerance is 1e-12 and no gain
+// leaves the kernel), the rebound losses in force at each point (ray.py:350-362), then "last write wins" through the LDS
+// hash cell -> last step exactly as rt2d_heatmap_kernel does it, the owning point depositing its value with one atomic.
+#define TAIL_THREADS 256
+#define TAIL_MAXC 8
+#define TAIL_CAP (TAIL_THREADS * TAIL_MAXC)      // 2048 points per ray (at 16 per thread the kernel needs 179 registers: two
+                                                 // workgroups per CU, 999 rays in two rounds)
+#define TAIL_HASH 4096                           // slots of the hash: load factor <= 1/2 without partitions
+struct TailArgs {
+    GainArgs g; const int32_t* status; const uint8_t* ray_mask;
+    HeatGeom geo; int64_t nx, nz; double* H; int64_t* n_dropped;
+    double freq; AlphaDesc ad; int32_t alpha_ok; int32_t pad;
+    unsigned long long* scratch;                 // optional: the two words rt2d_hm_max_kernel accumulates into, cleared here
+    double* overflow;                            // optional: set to 1 when a ray has more stored points than a workgroup holds
+    unsigned long long* dbg; int64_t dbg_cap;    // (RT2D_TAIL_LOG builds)
+};
+
+#ifdef RT2D_TAIL_LOG      // development aid: 100 MHz clock at the phase boundaries of every workgroup, into rt2d_debug_wave_log's buffer
+#define TAIL_STAMP(K) if (tid == 0 && t.dbg && blockIdx.x < (unsigned)t.dbg_cap) t.dbg[(size_t)blockIdx.x * 8 + (K)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TAIL_STAMP(K)
+#endif
+__attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(TAIL_THREADS) rt2d_small_tail_kernel(const TailArgs t) {
+    __shared__ int32_t s_hash[TAIL_HASH];       // cell -> its last step: a slot holds the STEP, the cell it stands for is s_cell[step]
+    __shared__ int32_t s_cell[TAIL_CAP + 1];
+    __shared__ int16_t s_slot[TAIL_CAP];        // the slot a candidate point ended up in (pass A), read back by pass B    // (28 KB of LDS and 128 registers per ray: four workgroups per CU, 999 rays resident at once)
+    __shared__ double s_part[TAIL_THREADS / RT2D_WAVE];
+    __shared__ int s_red[2];
+    extern __shared__ __attribute__((aligned(16))) double s_loss[];        // [cap] cumulative rebound loss, then int [cap] first point carrying it
+    const GainArgs& a = t.g;
+    int* s_at = reinterpret_cast<int*>(s_loss + a.rebound_cap);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // A thread reads one point of the ray, i.e. one 8-byte word of a 128-byte line that also holds the same point of the
+    // ray's 15 neighbours: workgroups go to the 8 XCDs round-robin, so rays are dealt in groups of 16 consecutive rays per
+    // XCD and a line is fetched into ONE L2 (grid: a multiple of 128, as in rt2d_heatmap_kernel)
+    const int64_t b_xcd = blockIdx.x & 7, b_in = blockIdx.x >> 3;
+    const int64_t r = ((b_in >> 4) * 8 + b_xcd) * 16 + (b_in & 15);
+    if (blockIdx.x == 0 && tid == 0 && t.scratch) { t.scratch[0] = 0ull; t.scratch[1] = 0ull; }
+    if (r >= a.n) return;
+    // everything that depends on r alone is asked for at once (one global round trip instead of a chain of them): status,
+    // mask, point count, the tile's bounds, the rebound count and -- whatever that count turns out to be -- this thread's
+    // entry of the rebound log (an entry beyond the count is allocated, unspecified, and not used)
+    const int st = t.status[r];
+    const int mk = t.ray_mask ? (int)t.ray_mask[r] : 1;
+    const int np_raw = a.n_pts[r];
+    const int64_t toff0 = a.tile_off[r >> 6], toff1 = a.tile_off[(r >> 6) + 1];
+    const int nreb_raw = a.n_rebounds[r];
+    double rb_vel = 1.0, rb_ang = 0.0, rb_z = 0.0; int rb_step = 0; int rb_surf = 0;
+    if (tid < a.rebound_cap) {
+        const int64_t kk = (int64_t)tid * a.n + r;
+        rb_vel = a.reb_velocity[kk]; rb_ang = a.reb_angle[kk]; rb_z = a.reb_pos_z[kk]; rb_step = a.reb_step[kk]; rb_surf = a.reb_surface[kk];
+    }
+    if (st != 0 || mk == 0) return;                                         // (the same for the whole workgroup)
+    const int np = (int)min((int64_t)np_raw, (toff1 - toff0) >> 6);         // rt2d_stored_pts
+    if (np <= 0) return;
+    if (np > TAIL_CAP) {                                                    // the map will be incomplete: the caller is told and bins the fan another way
+        if (tid == 0 && t.overflow) *t.overflow = 1.0;
+        return;
+    }
+    TAIL_STAMP(0)
+    const int64_t base = toff0 + (r & 63);
+    const int64_t size = t.nx * t.nz;
+    const int c = (np + TAIL_THREADS - 1) / TAIL_THREADS;                   // points per thread, <= TAIL_MAXC
+    const int i0 = tid * c;
+    // the chunk's points and the one before it, all loads in flight together
+    double xs[TAIL_MAXC + 1], zs[TAIL_MAXC + 1];
+#pragma unroll
+    for (int u = 0; u <= TAIL_MAXC; ++u) {
+        if (u <= c) {
+            const int i = min(max(i0 - 1 + u, 0), np - 1);
+            const int64_t o = base + (int64_t)i * RT2D_WAVE;
+            xs[u] = a.X[o]; zs[u] = a.Z[o];
+        } else { xs[u] = 0.0; zs[u] = 0.0; }
+    }
+    for (int i = tid; i < TAIL_HASH; i += TAIL_THREADS) s_hash[i] = -1;
+    if (tid < 2) s_red[tid] = 0;
+    if (tid == 0) s_cell[np] = -2;
+    // rebound losses of this ray (one thread per rebound; rebounds beyond TAIL_THREADS in a strided loop), then their running sum
+    const int nreb = min(nreb_raw, a.rebound_cap);
+    {
+        const double* gtab = a.blob + a.env.gain_off;
+        for (int k = tid; k < nreb; k += TAIL_THREADS) {
+            if (k >= TAIL_THREADS) {
+                const int64_t kk = (int64_t)k * a.n + r;
+                rb_vel = a.reb_velocity[kk]; rb_ang = a.reb_angle[kk]; rb_z = a.reb_pos_z[kk]; rb_step = a.reb_step[kk]; rb_surf = a.reb_surface[kk];
+            }
+            const double wavelength = rb_vel / t.freq;
+            const double rc = (rb_surf == RT2D_SURFACE_SEDIMENT)
+                ? rt2d_refcoef_sediment(wavelength, rt2d_eval_quad(gtab, a.env.imp, rb_z, nullptr))
+                : rt2d_refcoef_surface(wavelength, rb_ang);
+            s_loss[k] = 10 * log10(rc);
+            s_at[k] = rb_step + 1;
+        }
+    }
+    TAIL_STAMP(1)
+    // cells and dG of the chunk; gl[u] = sum of the chunk's dG up to and including point i0 + u
+    const double f = t.freq / 1000, ff = f * f;                            // model_absorption.py:32
+    double gl[TAIL_MAXC];
+    double run = 0.0;
+    int n_drop = 0;
+#pragma unroll
+    for (int u = 0; u < TAIL_MAXC; ++u) {
+        gl[u] = run;
+        const int i = i0 + u;
+        if (u < c && i < np) {
+            const double x = xs[u + 1], z = zs[u + 1], xp = xs[u], zp = zs[u];
+            const int32_t cell = (int32_t)rt2d_cell(t.geo, x, z, t.nz, size);
+            s_cell[i] = cell;
+            n_drop += cell < 0;
+            if (i >= 1) {
+                const double ddx = x - xp, ddz = z - zp;
+                const double dL = rt2d_sqrt_fast(fma(ddx, ddx, ddz * ddz));
+                double pa;
+                bool have = false;
+                if (t.alpha_ok) {
+                    int j = (int)((zp - t.ad.x0) * t.ad.inv_h);
+                    j = min(max(j, 0), t.ad.n_pieces - 1);
+                    const double* rec = t.ad.tab + (size_t)j * ALPHA_REC;
+                    const double lo = rec[0], hi = rec[1];
+                    const double d = zp - lo;
+                    pa = fma(rec[9], d, rec[8]);
+                    pa = fma(pa, d, rec[7]); pa = fma(pa, d, rec[6]); pa = fma(pa, d, rec[5]); pa = fma(pa, d, rec[4]);
+                    pa = fma(pa, d, rec[3]); pa = fma(pa, d, rec[2]);
+                    have = (zp >= lo) & (zp < hi);
+                }
+                if (!have) {
+                    double r19[20];
+                    rt2d_lookup<19>(a.blob + a.env.gain_off, a.env.absorb, zp, r19);
+                    const double al = -rt2d_alpha_fast(r19, zp - r19[0], ff);
+                    const double q = al * 0.001;
+                    pa = fma(fma(-q, 1000.0, al), 0.001, q);
+                }
+                run = fma(pa, dL, run);                                     // ray.py:346-347
+            }
+            gl[u] = run;
+        }
+    }
+    TAIL_STAMP(2)
+    // exclusive scan of the chunk sums over the workgroup
+    double incl = run;
+#pragma unroll
+    for (int off = 1; off < RT2D_WAVE; off <<= 1) {
+        const double up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == RT2D_WAVE - 1) s_part[wv] = incl;
+    __syncthreads();                                                        // s_part, s_cell, s_loss / s_at, s_hash, s_red
+    double offset = incl - run;
+    for (int k = 0; k < wv; ++k) offset += s_part[k];
+    if (tid == 0) { double A = 0.0; for (int k = 0; k < nreb; ++k) { A += s_loss[k]; s_loss[k] = A; } }
+    TAIL_STAMP(3)
+    // candidates: last point of a run of equal cells
+    unsigned cand = 0u;                                                     // bit u: point i0 + u is the last of its run of equal cells
+#pragma unroll
+    for (int u = 0; u < TAIL_MAXC; ++u) {
+        const int i = i0 + u;
+        if (u < c && i < np) { const int32_t cell = s_cell[i]; cand |= (unsigned)((cell >= 0) & (s_cell[i + 1] != cell)) << u; }
+    }
+    for (int off = 32; off > 0; off >>= 1) n_drop += __shfl_xor(n_drop, off);
+    if (lane == 0 && n_drop) atomicAdd(&s_red[1], n_drop);
+    __syncthreads();                                                        // s_red, the summed s_loss
+    n_drop = s_red[1];
+    if (tid == 0 && n_drop && t.n_dropped) atomicAdd((unsigned long long*)t.n_dropped, (unsigned long long)n_drop);
+    // gain of every point of the chunk: running sum + the loss in force (ray.py:360-362)
+    {
+        int k = 0; double A = 0.0;
+#pragma unroll
+        for (int u = 0; u < TAIL_MAXC; ++u) {
+            const int i = i0 + u;
+            if (u < c && i < np) {
+                while (k < nreb && s_at[k] <= i) { A = s_loss[k]; ++k; }
+                gl[u] = (offset + gl[u]) + A;
+            }
+        }
+    }
+    TAIL_STAMP(4)
+    // At most TAIL_CAP candidates in TAIL_HASH = 2 TAIL_CAP slots: load factor <= 1/2, no partitions.
+    // pass A: cell -> last step.  One loop with every lane busy: a lane makes ONE probe of its current candidate per
+    // iteration and moves on to its next candidate when that one is placed -- the wave is done after the max over lanes of
+    // their probes, not after the sum over points of the longest probe sequence.
+    const uint32_t mask = TAIL_HASH - 1;
+    {
+        unsigned todo = cand;
+        bool probing = false;
+        int i = 0; int32_t cell = 0; uint32_t slot = 0;
+        while (todo != 0u || probing) {
+            if (!probing) {
+                const int u = __ffs(todo) - 1;
+                todo &= todo - 1u;
+                i = i0 + u; cell = s_cell[i];
+                slot = rt2d_hash32((uint32_t)cell) & mask; probing = true;
+            }
+            const int32_t old = atomicCAS(&s_hash[slot], -1, i);
+            // (a slot's step only ever changes to a later step of the same cell: s_cell[old] names the slot's cell for good)
+            if (old == -1) { s_slot[i] = (int16_t)slot; probing = false; }
+            else if (s_cell[old] == cell) { atomicMax(&s_hash[slot], i); s_slot[i] = (int16_t)slot; probing = false; }
+            else slot = (slot + 1) & mask;
+        }
+    }
+    __syncthreads();
+    TAIL_STAMP(5)
+    // pass B: the step that owns its cell deposits (simulation.py:129-131)
+#pragma unroll
+    for (int u = 0; u < TAIL_MAXC; ++u) {
+        if (!((cand >> u) & 1u)) continue;
+        const int i = i0 + u;
+        if (s_hash[(uint16_t)s_slot[i]] == i) atomicAdd(&t.H[s_cell[i]], rt2d_heat_val(gl[u]));      // ray.py:317, simulation.py:129
+    }
+    TAIL_STAMP(6)
+}
+
 // presentation (simulation.py:133-138)
 // np.max over the map: doubles of either sign are ordered through a key whose unsigned order is the numbers' order
 // (sign bit flipped for values >= 0, all bits flipped for negative ones), so one 64-bit atomicMax per wave does it and a
@@ -3830,6 +4046,62 @@ int32_t rt2d_heatmap_finalize(const double* H, const int32_t* shape, double cuto
     const int64_t blocks = (size + block - 1) / block;
     hipLaunchKernelGGL(rt2d_hm_max_kernel, dim3((unsigned)(blocks < 128 ? blocks : 128)), dim3(block), 0, stream,     // few waves: each ends in an atomic on one word
                        H, size, (unsigned long long*)scratch);
+    hipLaunchKernelGGL(rt2d_hm_finalize_kernel, dim3((unsigned)blocks), dim3(block), 0, stream,
+                       H, nx, nz, cutoff, reduction_power, (const unsigned long long*)scratch, out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int32_t rt2d_small_fan_heatmap(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                               const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, int64_t max_pts, double freq,
+                               const uint8_t* ray_mask, const int32_t* res, const int32_t* shape, double* H, int64_t* n_dropped,
+                               double cutoff, double reduction_power, double* out, double* scratch, double* overflow, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!env || !X || !Z || !tile_off || !n_pts || !reb || !res || !shape || !H) return fail("rt2d_small_fan_heatmap: null argument");
+    if (!reb->status || !reb->n_rebounds || !reb->reb_step || !reb->reb_surface || !reb->reb_velocity || !reb->reb_angle || !reb->reb_pos_z)
+        return fail("rt2d_small_fan_heatmap: status and the rebound log (n_rebounds, reb_step, reb_surface, reb_velocity, reb_angle, reb_pos_z) are required");
+    if (n < 0 || rebound_cap < 0) return fail("rt2d_small_fan_heatmap: negative count");
+    if (n > 0x7fffffff) return fail("rt2d_small_fan_heatmap: too many rays for one launch");
+    if (max_pts > TAIL_CAP && !overflow)
+        return fail("rt2d_small_fan_heatmap: rays of up to %lld stored points may exceed the %d points a workgroup holds: pass `overflow` "
+                    "(and bin the fan with rt2d_gain + rt2d_heatmap_accumulate when it comes back set), or use those directly",
+                    (long long)max_pts, TAIL_CAP);
+    if (!(freq > 0)) return fail("rt2d_small_fan_heatmap: freq must be positive");
+    if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_small_fan_heatmap: resolution must be positive");
+    if (shape[0] <= 0 || shape[1] <= 0 || (int64_t)shape[0] * shape[1] >= (1ll << 31)) return fail("rt2d_small_fan_heatmap: bad shape");
+    if (out && !scratch) return fail("rt2d_small_fan_heatmap: the normalised map needs the two-double scratch");
+    const size_t lds = (size_t)(rebound_cap > 0 ? rebound_cap : 1) * 12 + 8;
+    if (lds > 15 * 1024) return fail("rt2d_small_fan_heatmap: rebound log of %d entries per ray does not fit beside the hash; "
+                                     "use rt2d_gain + rt2d_heatmap_accumulate", rebound_cap);
+    TailArgs t; memset(&t, 0, sizeof t);
+    GainArgs& a = t.g;
+    a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts;
+    a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
+    a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
+    a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1;
+    t.status = reb->status; t.ray_mask = ray_mask;
+    t.geo.res_x = res[0]; t.geo.res_z = res[1]; t.geo.rx = res[0]; t.geo.rz = res[1];
+    t.geo.inv_rx = 1.0 / res[0]; t.geo.inv_rz = 1.0 / res[1];
+    t.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
+    t.nx = shape[0]; t.nz = shape[1]; t.H = H; t.n_dropped = n_dropped; t.freq = freq;
+    t.scratch = out ? (unsigned long long*)scratch : nullptr;
+    t.overflow = overflow;
+    t.dbg = g_wave_log; t.dbg_cap = g_wave_log_cap / 8;
+    static const int lean_env = getenv("RT2D_GH_LEAN") ? atoi(getenv("RT2D_GH_LEAN")) : 1;
+    bool ok = false;
+    if (lean_env) { int32_t rc = alpha_table_for(env, freq, &t.ad, &ok); if (rc) return rc; }
+    t.alpha_ok = ok ? 1 : 0;
+    if (n > 0) {
+        hipLaunchKernelGGL(rt2d_small_tail_kernel, dim3((unsigned)((n + 127) / 128 * 128)), dim3(TAIL_THREADS), lds, stream, t);
+        HIP_OK(hipGetLastError());
+    } else if (out) {
+        HIP_OK(hipMemsetAsync(scratch, 0, 2 * sizeof(double), stream));
+    }
+    if (!out) return 0;
+    const int64_t nx = shape[0], nz = shape[1], size = nx * nz;
+    const int block = 256;
+    const int64_t blocks = (size + block - 1) / block;
+    hipLaunchKernelGGL(rt2d_hm_max_kernel, dim3((unsigned)(blocks < 128 ? blocks : 128)), dim3(block), 0, stream, H, size, (unsigned long long*)scratch);
     hipLaunchKernelGGL(rt2d_hm_finalize_kernel, dim3((unsigned)blocks), dim3(block), 0, stream,
                        H, nx, nz, cutoff, reduction_power, (const unsigned long long*)scratch, out);
     HIP_OK(hipGetLastError());

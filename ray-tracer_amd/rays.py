@@ -963,6 +963,48 @@ class RayFan:
                 bin_maps(0, len(freqs))
             self._last_slow = work
 
+    SMALL_TAIL_MAX_RAYS = int(os.environ.get('RT2D_SMALL_TAIL_MAX_RAYS', 6000))     # (0: never)
+    SMALL_TAIL_MAX_PTS = 2048
+
+    def small_tail_room(self, freq, policy=True):
+        """Upper bound of the stored points per ray if rt2d_small_fan_heatmap may bin this fan (a small stored fan whose gain at
+        freq does not exist yet and whose rays fit a workgroup), else 0.  Known on the host without waiting for the cast.
+        policy: also require what makes it the better choice -- a fan below the tile kernel's threshold (HEATMAP_FAST_MIN_RAYS,
+        the fans the general one-workgroup-per-ray binner would take)."""
+        if not self.store or self.n == 0 or freq in self.G:
+            return 0
+        if policy and self.n > min(self.SMALL_TAIL_MAX_RAYS, HEATMAP_FAST_MIN_RAYS):
+            return 0
+        if self.padded:
+            room = int(self._room)
+        elif self._summary is not None:
+            room = int(self._summary[1]) // TILE
+        else:
+            return 0
+        if self.rebound_cap * 12 + 8 > 15 * 1024:
+            return 0
+        if room > self.SMALL_TAIL_MAX_PTS and not (self._pending and self.padded):
+            return 0              # (a fresh single-pass cast may have more ROOM than that: the kernel reports a ray that is longer
+                                  #  in the word behind the fan's summary, which the caller reads anyway -- validate())
+        return room
+
+    def heatmap_small(self, H, res, shape, freq=1, ray_mask=None, dropped=None, out=None, scratch=None, cutoff=.02, reduction_power=.5):
+        """Gain at freq and binning of every error-free ray in ONE launch (rt2d_small_fan_heatmap: one workgroup per ray, no
+        gain array), plus the normalised map into `out` when given.  Same map as populate(freq) + heatmap_accumulate."""
+        torch = _torch()
+        room = self.small_tail_room(freq, policy=False)
+        if not room:
+            raise _lib.Rt2dError('heatmap_small: not a stored fan whose rays fit a workgroup (see RayFan.small_tail_room)')
+        with torch.cuda.device(self.device):
+            res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
+            shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
+            _lib.check(_lib.lib().rt2d_small_fan_heatmap(
+                self.env.device_handle(self.device.index), self.X.data_ptr(), self.Z.data_ptr(), self.tile_off.data_ptr(),
+                self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap, self.n, room, float(freq), _ptr(ray_mask), res_c, shape_c,
+                H.data_ptr(), _ptr(dropped), float(cutoff), float(reduction_power), _ptr(out), _ptr(scratch),
+                self._summary_dev[8:].data_ptr() if room > self.SMALL_TAIL_MAX_PTS else None, _raw_stream()))
+        self._last_slow = self.n
+
     @property
     def last_slow_rays(self):
         """Rays of the last heatmap_accumulate* call that went through the general (one workgroup per ray) kernel."""

@@ -161,6 +161,7 @@ class Simulation2D:
             cells = int(shape_b[0]) * int(shape_b[1])
             zeroed = torch.zeros(cells + 1, dtype=torch.float64, device=device)      # the map and the dropped-points counter: one fill
             H, dropped = zeroed[:cells], zeroed[cells:].view(torch.int64)
+            out_b, scratch, finalized = None, None, False
             if bad:
                 pass
             elif lazy:
@@ -169,6 +170,17 @@ class Simulation2D:
                     if not dist_on:
                         return None
                     bad = True
+            elif (kwargs.get('fast', True) and kwargs.get('small', True) and kwargs.get('stream', None) is None
+                  and fan.small_tail_room(kwargs.get('freq', 1))):
+                # a small fan: gain + binning of every ray in ONE launch (no gain array), and -- when nothing has to be
+                # exchanged between ranks first -- max + normalisation queued by the same call
+                if finalize and not dist_on:
+                    out_b = torch.empty((int(shape_b[1]), int(shape_b[0])), dtype=torch.float64, device=device)
+                    scratch = torch.empty(2, dtype=torch.float64, device=device)
+                    finalized = True
+                fan.heatmap_small(H, res, shape_b, freq=kwargs.get('freq', 1), dropped=dropped, out=out_b if finalized else None,
+                                  scratch=scratch if finalized else None, cutoff=float(kwargs.get('cutoff', .02)),
+                                  reduction_power=float(kwargs.get('reduction_power', .5)))
             else:
                 mask = fan._ok_mask if getattr(fan, '_ok_mask', None) is not None else (fan.status == 0).to(torch.uint8)
                 fan.heatmap_accumulate(H, res, shape_b, freq=kwargs.get('freq', 1), ray_mask=mask, dropped=dropped,
@@ -193,8 +205,7 @@ class Simulation2D:
                 zeroed[cells] = dropped[0].to(torch.float64)                      # (the counter travels as a double in the same sum)
                 parallel.allreduce_heatmap(zeroed)
                 dropped = zeroed[cells:].round().to(torch.int64)
-            out_b = None
-            if finalize:
+            if finalize and not finalized:
                 out_b = torch.empty((int(shape_b[1]), int(shape_b[0])), dtype=torch.float64, device=device)
                 scratch = torch.empty(2, dtype=torch.float64, device=device)
                 shape_c = (C.c_int32 * 2)(int(shape_b[0]), int(shape_b[1]))
@@ -256,6 +267,10 @@ class Simulation2D:
             if len(idx) != fan.n:
                 mask = torch.zeros(fan.n, dtype=torch.uint8, device=device)
                 mask[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=device)] = 1
+            if (kwargs.get('fast', True) and kwargs.get('small', True) and kwargs.get('stream', None) is None
+                    and fan.store and not fan._pending and fan.small_tail_room(freq)):
+                fan.heatmap_small(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped)      # one launch: gain + binning
+                continue
             fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True),
                                    hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
         if dist_on:                                                       # C2: sum of the ranks' maps

@@ -418,3 +418,61 @@ def test_multi_frequency_binning_on_a_large_fan(rt):
         fin = np.isfinite(one)
         assert np.array_equal(np.isfinite(both[f]), fin) and not np.isnan(both[f][fin]).any()
         assert np.abs(both[f] - one)[fin].max() < 1e-12
+
+
+@pytest.mark.parametrize('name,freq', [('c1_flat250', 1), ('c2_fan999', 1), ('c3_bathy999', 1), ('c2_fan999', 4000.), ('t2_single', 1000.)])
+def test_small_fan_heatmap_in_one_launch(rt, name, freq, monkeypatch):
+    """rt2d_small_fan_heatmap (gain + binning of a ray by one workgroup, then max + normalisation: what Simulation2D.heatmap
+    runs for a small fan) against rt2d_gain + rt2d_heatmap_accumulate + rt2d_heatmap_finalize of the same stored fan, which
+    the tests above pin to the oracle and the reference: every cell to 1e-12, same dropped-point count, and no gain
+    array is made.  Through the C ABI directly and through the product API.  t2_single: a ray of 100 001 points does not
+    fit a workgroup -- the kernel says so in the word behind the fan's summary and the product bins the fan the other way."""
+    import torch
+    from ray_tracer_amd import rays
+    g = common.load(name)
+    fan, env = _cast(rt, g)                        # (fresh single-pass cast: its summary has not been read yet)
+    shape = (1610, 210) if name == 't2_single' else (1600, 80)
+    cells = shape[0] * shape[1]
+    Ha = torch.zeros(cells, dtype=torch.float64, device='cuda'); Hb = torch.zeros_like(Ha)
+    da = torch.zeros(1, dtype=torch.int64, device='cuda'); db = torch.zeros_like(da)
+    assert fan.small_tail_room(freq, policy=False) > 0
+    out = torch.empty((shape[1], shape[0]), dtype=torch.float64, device='cuda')
+    scratch = torch.empty(2, dtype=torch.float64, device='cuda')
+    fan.heatmap_small(Ha, (50, 25), shape, freq=freq, dropped=da, out=out, scratch=scratch, cutoff=.1, reduction_power=.5)
+    assert freq not in fan.G
+    assert fan.validate() is False
+    monkeypatch.setattr(rays, 'HEATMAP_FAST_MIN_RAYS', 6000)      # (the test session sets the tile kernel's threshold to 0)
+    if name == 't2_single':
+        assert fan._onepass_overflow and float(Ha.sum()) == 0.0
+        assert fan.small_tail_room(freq, policy=False) == 0        # ... and once the summary is known the fan no longer qualifies
+    else:
+        assert not fan._onepass_overflow
+        mask = (fan.status == 0).to(torch.uint8)
+        fan.heatmap_accumulate(Hb, (50, 25), shape, freq=freq, ray_mask=mask, dropped=db, stream=False)
+        Ha_, Hb_ = Ha.cpu().numpy(), Hb.cpu().numpy()
+        assert int(da.item()) == int(db.item())
+        assert np.array_equal(Ha_ == 0, Hb_ == 0) and np.array_equal(np.isinf(Ha_), np.isinf(Hb_)) and not np.isnan(Ha_).any()
+        both = np.isfinite(Hb_) & (Hb_ != 0)
+        assert (np.abs(Ha_ - Hb_)[both] / np.abs(Hb_[both])).max() < 1e-12
+        ref = torch.empty_like(out)
+        rt._lib.check(rt._lib.lib().rt2d_heatmap_finalize(Hb.data_ptr(), (C.c_int32 * 2)(*shape), .1, .5, ref.data_ptr(), scratch.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream))
+        o, q = out.cpu().numpy(), ref.cpu().numpy()
+        fin = np.isfinite(q)
+        assert np.array_equal(np.isfinite(o), fin) and np.abs(o[fin] - q[fin]).max() < 1e-12
+    # the product API takes this path for a freshly cast small fan (below the tile kernel's threshold), and the general
+    # (three-launch) path on request -- or by itself when a ray turns out too long
+    sim = rt.Simulation2D(env, g['fan_source'])
+    sim.cast(g['fan_angles'], **common.prop_kwargs(g))
+    a = sim.heatmap(resolution=[50, 25], cutoff=.1, freq=freq)
+    sim2 = rt.Simulation2D(env, g['fan_source'])
+    sim2.cast(g['fan_angles'], **common.prop_kwargs(g))
+    b = sim2.heatmap(resolution=[50, 25], cutoff=.1, freq=freq, small=False)
+    fin = np.isfinite(b)
+    assert a.shape == b.shape and np.array_equal(np.isfinite(a), fin) and np.abs(a[fin] - b[fin]).max() < 1e-12
+    # argument checks of the entry point: a room beyond 2048 points needs the overflow word
+    with pytest.raises(rt._lib.Rt2dError, match='2048'):
+        rt._lib.check(rt._lib.lib().rt2d_small_fan_heatmap(
+            env.device_handle(0), fan.X.data_ptr(), fan.Z.data_ptr(), fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), C.byref(fan._out),
+            fan.rebound_cap, fan.n, 5000, 1.0, None, (C.c_int32 * 2)(50, 25), (C.c_int32 * 2)(*shape), Ha.data_ptr(), None, .1, .5, None, None,
+            None, None))
