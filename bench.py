@@ -434,6 +434,8 @@ def default_resolution_block(rt, torch, env_c2, device, rays, reps=2):
     steps = ray_steps_of(fan.n_pts, fan.status)
     default_is_fused = n < rays_mod.CHUNKED_MIN_RAYS
     other = 'chunked' if default_is_fused else 'fused'
+    del fan3
+    torch.cuda.empty_cache()          # (the chunked path wants a third of the FREE memory per chunk: give back what the blocks above cached)
     t_other, (fan_o, hm_o) = timed(lambda: run(other), 1)
     blk = {
         'workload': f'C2 environment, {n} rays -(j+1) 0.999/{n} rad, defaults, Simulation2D.cast(store=False) + heatmap()',

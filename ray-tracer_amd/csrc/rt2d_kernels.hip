@@ -2413,6 +2413,12 @@ struct HeatArgs {
 #ifndef HM_UNROLL
 #define HM_UNROLL 4      // measured: 8 rows in flight cost registers and 1.7 ms per 1M rays
 #endif
+#ifndef HM_STAGE
+#define HM_STAGE 256         // slots of a wave's staging table (several maps per pass)
+#endif
+#ifndef HM_STAGE_ROWS
+#define HM_STAGE_ROWS 16     // rows of the walk between two flushes of it (a multiple of HM_UNROLL)
+#endif
 template <int MW, int FB>     // MW: 64-bit mask words per lane (rows nz <= 64 * MW); FB: maps (frequencies) binned per pass
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
     // FB > 1: blockIdx.y picks a group of FB frequencies.  The cells of a point, "first time this (column, row) is seen" and
@@ -2428,6 +2434,37 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
         Hk[k] = a.H + (int64_t)f * a.map_stride;
     }
     const int nf = (FB > 1) ? min(FB, a.n_freqs - f0) : 1;            // ... but only deposits the first nf
+    // FB > 1: the maps of several frequencies are bound by the f64 atomics of the L2s (one per run of equal cells per map: a
+    // tile's rays take steps of different lengths, so at one step they sit in several columns, and the same cells come up
+    // again a few steps later from other lanes).  Each wave therefore stages its deposits in a table of its own in LDS
+    // (HM_STAGE slots: cell -> FB sums, direct-mapped, ds_add_f64) and sends the table to the maps every HM_STAGE_ROWS rows
+    // of its walk: one atomic per (cell, map) of the window instead of one per (run, step, map).  The table is private to the
+    // wave and the wave runs in lockstep: no barrier anywhere.  A deposit whose slot holds another cell goes to the map directly.
+    constexpr int STAGE = (FB > 1) ? HM_STAGE : 1;
+    __shared__ int32_t s_stage_key[(FB > 1) ? 4 : 1][STAGE];
+    __shared__ double s_stage_val[(FB > 1) ? 4 : 1][STAGE * FB];
+    int32_t* const st_key = s_stage_key[(FB > 1) ? (threadIdx.x / RT2D_WAVE) : 0];
+    double* const st_val = s_stage_val[(FB > 1) ? (threadIdx.x / RT2D_WAVE) : 0];
+    if (FB > 1) {
+        for (int q = threadIdx.x & 63; q < STAGE; q += RT2D_WAVE) {
+            st_key[q] = -1;
+#pragma unroll
+            for (int kk = 0; kk < FB; ++kk) st_val[q * FB + kk] = 0.0;
+        }
+    }
+    auto stage_flush = [&]() {
+        if (FB == 1) return;
+        for (int q = threadIdx.x & 63; q < STAGE; q += RT2D_WAVE) {
+            const int32_t key = st_key[q];
+            if (key < 0) continue;
+#pragma unroll
+            for (int kk = 0; kk < FB; ++kk) {
+                if (kk < nf) atomicAdd(&Hk[kk][key], st_val[q * FB + kk]);
+                st_val[q * FB + kk] = 0.0;
+            }
+            st_key[q] = -1;
+        }
+    };
     // Fans of 10^4..10^5 rays have too few tiles to give a SIMD more than one wave, and then the kernel's time is the
     // length of one wave's walk.  Such a tile is walked by `split` waves, each taking a contiguous range of ROWS (see
     // "rows of this wave" below); tiles with unchecked rays are walked whole by their first wave.
@@ -2571,6 +2608,14 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             // equal cells across the wave are summed and the last lane of each run issues ONE atomic per map.
             DepositRuns runs;
             if (!runs.init(fresh, cell, lane)) continue;
+            // (FB > 1) the slot of the wave's staging table for this run's cell: claimed if free, shared if it is this cell's
+            bool staged = false;
+            int st_slot = 0;
+            if (FB > 1 && runs.tail) {
+                st_slot = (int)(rt2d_hash32((uint32_t)cell) & (uint32_t)(STAGE - 1));
+                const int32_t old = atomicCAS(&st_key[st_slot], -1, cell);
+                staged = old == -1 || old == cell;
+            }
 #pragma unroll
             for (int k = 0; k < FB; ++k) {
                 if (k >= nf) break;
@@ -2582,9 +2627,13 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
                     else late |= 1u << (u * FB + k);        // adds 0 to its run here, the real value below
                 }
                 const double v = runs.sum(val);
-                if (runs.tail) atomicAdd(&Hk[k][cell], v);
+                if (runs.tail) {
+                    if (FB > 1 && staged) unsafeAtomicAdd(&st_val[st_slot * FB + k], v);
+                    else atomicAdd(&Hk[k][cell], v);
+                }
             }
         }
+        if (FB > 1 && (((row_hi - 1 - s0) / HM_UNROLL) % (HM_STAGE_ROWS / HM_UNROLL)) == (HM_STAGE_ROWS / HM_UNROLL) - 1) stage_flush();
         // gains beyond +-3000 dB (a surface coefficient that underflowed to 0 at high frequency): the pow pair of the
         // reference, kept out of the loop above and present once in the program
         while (__builtin_expect(late != 0u, 0)) {
@@ -2599,6 +2648,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             atomicAdd(&Hm[cell], rt2d_heat_val_pows(g));
         }
     }
+    stage_flush();
 }
 
 // General path: one workgroup of HM_THREADS per ray, any trajectory.  The cell of every point is computed once into LDS

@@ -44,11 +44,17 @@ SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat 
 LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
 
 
+_TORCH = None
+
+
 def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise _lib.Rt2dError('no GPU visible to torch: this package computes on MI355X only (no CPU fallback)')
-    return torch
+    global _TORCH
+    if _TORCH is None:                    # (checked once: torch.cuda.is_available() costs ~2 us, and a cast asks five times)
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.Rt2dError('no GPU visible to torch: this package computes on MI355X only (no CPU fallback)')
+        _TORCH = torch
+    return _TORCH
 
 
 def _ptr(t):
