@@ -2434,12 +2434,16 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
         Hk[k] = a.H + (int64_t)f * a.map_stride;
     }
     const int nf = (FB > 1) ? min(FB, a.n_freqs - f0) : 1;            // ... but only deposits the first nf
-    // FB > 1: the maps of several frequencies are bound by the f64 atomics of the L2s (one per run of equal cells per map: a
-    // tile's rays take steps of different lengths, so at one step they sit in several columns, and the same cells come up
-    // again a few steps later from other lanes).  Each wave therefore stages its deposits in a table of its own in LDS
-    // (HM_STAGE slots: cell -> FB sums, direct-mapped, ds_add_f64) and sends the table to the maps every HM_STAGE_ROWS rows
-    // of its walk: one atomic per (cell, map) of the window instead of one per (run, step, map).  The table is private to the
-    // wave and the wave runs in lockstep: no barrier anywhere.  A deposit whose slot holds another cell goes to the map directly.
+    // FB > 1: the maps of several frequencies are bound by the f64 atomics of the L2s (one per run of equal cells per map).
+    // Each wave stages its deposits in a table of its own in LDS (HM_STAGE slots: cell -> FB sums, direct-mapped,
+    // ds_add_f64) and sends the table to the maps every HM_STAGE_ROWS rows of its walk.  The table is private to the wave
+    // and the wave runs in lockstep: no barrier anywhere.  A deposit whose slot holds another cell goes to the map directly.
+    // What it buys is modest and measured (64 maps x 65 536 rays: 375 M -> 338 M atomics, 0.635 -> 0.607 ms per map): inside
+    // a tile a cell hardly ever comes up again at another step -- every ray advances by exactly dx_max in x or dz_max in z
+    // per step, so the rays of a tile share the column or the row of a step and leave it together -- and where a tile's rays
+    // sit in many cells at one step they have been scattered by a dozen rebounds and share cells with nobody.  Tried beyond
+    // it: ONE table for four adjacent tiles per workgroup, flushed per window of 16 absolute rows between barriers: 252 M
+    // atomics (-25 %) but 18.4 ms against 17.6 for the launch (the barriers), 0.645 ms per map: not kept.
     constexpr int STAGE = (FB > 1) ? HM_STAGE : 1;
     __shared__ int32_t s_stage_key[(FB > 1) ? 4 : 1][STAGE];
     __shared__ double s_stage_val[(FB > 1) ? 4 : 1][STAGE * FB];
@@ -3259,7 +3263,10 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
         a.lanes = lanes;
         // (experiment: the same rays per CU spread over more waves of fewer lanes, RT2D_CAST_LANES = lanes per wave)
         static const int lanes_env = getenv("RT2D_CAST_LANES") ? atoi(getenv("RT2D_CAST_LANES")) : 0;
-        if (lanes_env >= 1 && lanes_env < lanes && (lanes_env & (lanes_env - 1)) == 0) {
+        // (measured on the refine cones, 4590 near-vertical rays of up to 100 000 steps: 669 / 800 / 891 ms per three
+        // iterations with 32 / 16 / 8 rays per wave -- co-resident waves cost more than shared rebound branches)
+        if (lanes_env >= 1 && lanes_env < lanes && (lanes_env & (lanes_env - 1)) == 0 &&
+            (lanes / lanes_env) <= (hybrid || !in_lds ? 16 : RT2D_TAB1_MAX_WAVES)) {          // within the instance's launch bound
             block = (lanes / lanes_env) * RT2D_WAVE;
             a.lanes = lanes_env;
         }
