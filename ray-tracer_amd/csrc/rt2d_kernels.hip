@@ -1582,6 +1582,23 @@ __global__ void __launch_bounds__(256) rt2d_reb_loss_kernel(const GainArgs a, do
     loss[((int64_t)blockIdx.y * a.rebound_cap + k) * a.n + r] = 10 * log10(rc);
 }
 
+// Rays with hundreds or thousands of rebounds (no rebound limit at the reference's default step sizes: a ray that hugs the
+// surface rebounds every few steps) have a rebound log too long for the LDS of the scan kernels.  Their losses are ADDED
+// INTO the per-point dG array instead -- the loss of rebound k at point reb_step + 1, the first point that carries it
+// (ray.py:360-362), one thread per (ray, rebound, frequency); two rebounds never share a step -- and the scan then runs
+// without a log.  Same sum, another order of additions (the scan kernels' own order is not the reference's either).
+__global__ void __launch_bounds__(256) rt2d_reb_scatter_kernel(const GainArgs a, const double* loss) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n * a.rebound_cap) return;
+    const int64_t r = idx % a.n;
+    const int k = (int)(idx / a.n);
+    if (k >= min(a.n_rebounds[r], a.rebound_cap)) return;
+    const int at = a.reb_step[(int64_t)k * a.n + r] + 1;
+    if (at >= rt2d_stored_pts(a.n_pts, a.tile_off, r)) return;
+    const int64_t o = a.tile_off[r >> 6] + (r & 63) + (int64_t)at * RT2D_WAVE;
+    a.G[(int64_t)blockIdx.y * a.total + o] += loss[((int64_t)blockIdx.y * a.rebound_cap + k) * a.n + r];
+}
+
 template <int FCH, bool LOSS>
 __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
@@ -3562,6 +3579,29 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     // limit at the reference's default step sizes) -- the ray-sequential loop below needs 1.1 us per point on such fans
     const bool use_part = part_env == 1 || (part_env != 0 && n_tiles * (int64_t)n_freqs * (RT2D_WAVE / GAIN_PART_RAYS) <= 512);
     const size_t part_lds = 3 * (size_t)GAIN_SCAN_THREADS * 8 + (size_t)(rebound_cap > 0 ? rebound_cap : 1) * GAIN_PART_RAYS * 12;
+    // (the log does not fit: losses scattered into dG by their own kernel, the scan runs without a log)
+    const bool scatter = G && two_phase && use_part && part_lds > RT2D_LDS_BUDGET && loss_ws && rebound_cap > 0;
+    if (scatter) {
+        const unsigned split = (unsigned)(n_tiles >= 512 ? 4 : (2048 + n_tiles - 1) / n_tiles);
+        dim3 grid1((unsigned)n_tiles, split, (unsigned)((n_freqs + fch - 1) / fch));
+        void (*k1)(const GainArgs) = fch == 8 ? rt2d_gain_dg_kernel<8> : fch == 4 ? rt2d_gain_dg_kernel<4>
+                                    : fch == 2 ? rt2d_gain_dg_kernel<2> : rt2d_gain_dg_kernel<1>;
+        ALLOW_LDS(k1, lds);
+        hipLaunchKernelGGL(k1, grid1, dim3(256), lds, (hipStream_t)stream, a);
+        const int64_t pairs = n * rebound_cap;
+        hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)n_freqs), dim3(256), 0,
+                           (hipStream_t)stream, a, loss_ws, 0.0);
+        hipLaunchKernelGGL(rt2d_reb_scatter_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)n_freqs), dim3(256), 0,
+                           (hipStream_t)stream, a, (const double*)loss_ws);
+        GainArgs b = a;
+        b.rebound_cap = 0;
+        const size_t lds0 = 3 * (size_t)GAIN_SCAN_THREADS * 8 + GAIN_PART_RAYS * 12;
+        ALLOW_LDS(rt2d_gain_scan_part_kernel, lds0);
+        hipLaunchKernelGGL(rt2d_gain_scan_part_kernel, dim3((unsigned)n_tiles, (unsigned)n_freqs, RT2D_WAVE / GAIN_PART_RAYS),
+                           dim3(GAIN_SCAN_THREADS), lds0, (hipStream_t)stream, b);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
     if (G && two_phase && (use_part ? part_lds : scan_lds) <= RT2D_LDS_BUDGET) {
         // small fan: per-point dG on the whole chip, then the running sums (see rt2d_gain_dg_kernel)
         const unsigned split = (unsigned)(n_tiles >= 512 ? 4 : (2048 + n_tiles - 1) / n_tiles);

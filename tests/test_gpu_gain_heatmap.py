@@ -476,3 +476,37 @@ def test_small_fan_heatmap_in_one_launch(rt, name, freq, monkeypatch):
             env.device_handle(0), fan.X.data_ptr(), fan.Z.data_ptr(), fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), C.byref(fan._out),
             fan.rebound_cap, fan.n, 5000, 1.0, None, (C.c_int32 * 2)(50, 25), (C.c_int32 * 2)(*shape), Ha.data_ptr(), None, .1, .5, None, None,
             None, None))
+
+
+def test_gain_of_rays_with_thousands_of_rebounds(rt, orc):
+    """No rebound limit in 10 m of water: steep rays rebound every few steps and log over a thousand rebounds, more than the
+    LDS of the scan kernels holds.  The small-fan gain then adds the losses into the per-point dG (rt2d_reb_scatter_kernel)
+    and scans without a log; against the oracle on the GPU's own points and log, and against the ray-sequential kernel."""
+    xs = np.linspace(0., 6000., 61)
+    env = rt.Environment2D((xs, np.full_like(xs, -10.)), (np.array([0., 6000.]), np.array([0., 0.])),
+                           np.array([0., -31.]), np.array([6000., 1.]))
+    oenv = common.oracle_env_from_product(orc, env)
+    angles = np.linspace(-1.3, -0.9, 40)
+    kw = dict(dx_max=10., dz_max=20., n_rebounds_max=-1, n_steps_max=8000)
+    fan = rt.RayFan(env, np.array([0., -5.]), angles, **kw)
+    fan.validate()
+    assert int(fan.n_rebounds.max().item()) > 1400 and fan.rebound_cap > 1400
+    freqs = [1., 2500.]
+    fan.populate(*freqs)
+    rays = common.oracle_rays_from_fan(orc, rt, fan)
+    worst = 0.0
+    for i in range(0, fan.n, 3):
+        r = rays[i]
+        if r.status != 0:
+            continue
+        orc.post_ray(oenv, r)
+        for f in freqs:
+            G = orc.gain(oenv, r, f)
+            Gd = fan.ray_slice(fan.G[f], i).cpu().numpy()
+            assert np.array_equal(np.isfinite(G), np.isfinite(Gd))
+            m = np.isfinite(G)
+            worst = max(worst, (np.abs(G[m] - Gd[m]) / np.maximum(1e-6, np.abs(G[m]))).max(initial=0))
+            ge = fan.G_end[f][i].item()
+            assert Gd[-1] == ge or (np.isneginf(Gd[-1]) and np.isneginf(ge))
+    print(f'gain with the losses scattered into dG vs oracle: worst relative error {worst:.2e}')
+    assert worst < 1e-10
