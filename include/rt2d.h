@@ -45,6 +45,9 @@ extern "C" {
 #define RT2D_STOP_MAX_ITER      7
 #define RT2D_STOP_POWER_CUTOFF  8   /* opt-in extension, see Rt2dParams.power_cutoff */
 
+/* Rt2dParams.launch_hint */
+#define RT2D_LAUNCH_SMALL_LDS     1
+
 /* per-ray status */
 #define RT2D_RAY_OK               0
 #define RT2D_RAY_ERR_INTERP      -1  /* slope table queried outside its range: the reference raises
@@ -100,7 +103,10 @@ typedef struct {
     double  target[2];
     int32_t rebound_cap;     /* slots per ray in the rebound log arrays; a ray with more rebounds gets
                                 RT2D_RAY_ERR_REBOUND_LOG (n_rebounds_max+1 slots always suffice when bounded) */
-    int32_t reserved;
+    int32_t launch_hint;     /* 0: the library chooses the launch shape.  RT2D_LAUNCH_SMALL_LDS (1): this cast runs BESIDE a
+                                kernel whose workgroups hold most of every CU's LDS (the side rays of rt2d_cast_heatmap):
+                                only the sound-speed table is staged in LDS, floor and surface records come through the
+                                caches, so that its workgroups find room on the same CUs.  Results do not depend on it */
     double  power_cutoff;    /* <= 0: off (reference behaviour).  > 0: stop the ray at the first point whose
                                 transmittance 10^(G/10) at cutoff_freq falls below it (opt-in, SURVEY trap 2) */
     double  cutoff_freq;

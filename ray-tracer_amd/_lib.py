@@ -117,7 +117,7 @@ class Rt2dParams(C.Structure):
                 ('n_steps_max', C.c_int32), ('n_rebounds_max', C.c_int32),
                 ('backprop', C.c_int32), ('has_target', C.c_int32),
                 ('target', C.c_double * 2),
-                ('rebound_cap', C.c_int32), ('reserved', C.c_int32),
+                ('rebound_cap', C.c_int32), ('launch_hint', C.c_int32),
                 ('power_cutoff', C.c_double), ('cutoff_freq', C.c_double)]
 
 

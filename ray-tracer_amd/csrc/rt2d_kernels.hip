@@ -3263,8 +3263,13 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     const bool in_lds = cold + tab_bytes <= RT2D_LDS_BUDGET && tab_env != 0;
     static const int64_t n_cu_env = getenv("RT2D_CAST_CUS") ? atoll(getenv("RT2D_CAST_CUS")) : 0;
     const int64_t n_cu = n_cu_env > 0 ? n_cu_env : env->n_cu;
-    // large fans (more than one full wave per CU): sound speed in LDS, floor and surface through the caches (TAB = 2)
-    const bool hybrid = n > n_cu * RT2D_WAVE && cold + cz_bytes <= 32 * 1024 && tab_env != 0 && tab_env != 1;
+    // large fans (more than eight full waves per CU): sound speed in LDS, floor and surface through the caches (TAB = 2).
+    // Below that there are too few waves to hide the cache latency of a floor record whose neighbours in the wave are
+    // kilometres apart (count pass of 65 536 rays at the default step sizes 108 -> 78 ms with everything in LDS, 131 072
+    // rays 112 -> 82 ms; at dx_max 50 / dz_max 25: 32 768 rays stored 1.94 -> 1.42 ms, 65 536 1.88 -> 1.44, 131 072
+    // 1.74 -> 1.51, 262 144 2.15 -> 2.28).  RT2D_LAUNCH_SMALL_LDS asks for it whatever the size.
+    const bool small_lds = a.p.launch_hint == RT2D_LAUNCH_SMALL_LDS;
+    const bool hybrid = (n > n_cu * RT2D_WAVE * 8 || small_lds) && cold + cz_bytes <= 32 * 1024 && tab_env != 0 && tab_env != 1;
     const size_t lds = cold + (hybrid ? cz_bytes : in_lds ? tab_bytes : 0);
     // Launch shape.  Measured on MI355X (tools/microbench_lanes.py): a wave steps fastest when it is alone on its CU
     // (co-resident waves cost each other 0.4-0.7 us per step even on different SIMDs) and when few of its lanes are in
@@ -3290,11 +3295,13 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     } else {
         // smallest workgroup with which all workgroups are resident at once (LDS decides how many fit on a CU); with the
         // small LDS footprint of the hybrid mode: two waves per workgroup, ten workgroups per CU
+        // (fewer rays per wave here, i.e. more waves: no gain.  Count pass of 65 536 rays at the default step sizes with 64 /
+        // 32 / 16 rays per wave: 78 / 82 / 136 ms -- the longest wave is ONE ray that rebounds on almost every step)
         const int64_t waves = (n + RT2D_WAVE - 1) / RT2D_WAVE;
         const int64_t per_cu = lds > 0 ? (int64_t)((160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1) : 16;
         int wpb = 1;
         while (wpb < 16 && (waves + wpb - 1) / wpb > n_cu * per_cu) wpb *= 2;
-        if (hybrid) wpb = 2;
+        if (hybrid && !small_lds) wpb = 2;
         if (const char* w = getenv("RT2D_CAST_WPB")) { const int v = atoi(w); if (v >= 1 && v <= 16) wpb = v; }
         if (!hybrid && in_lds && wpb > RT2D_TAB1_MAX_WAVES) wpb = RT2D_TAB1_MAX_WAVES;     // that instance's launch bound
         block = wpb * RT2D_WAVE;
@@ -3432,8 +3439,10 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     if (waves > (loss ? RT2D_FUSE2_MAX_WAVES : RT2D_FUSE_MAX_WAVES)) waves = loss ? RT2D_FUSE2_MAX_WAVES : RT2D_FUSE_MAX_WAVES;
     static const int waves_env = getenv("RT2D_FUSE_WAVES") ? atoi(getenv("RT2D_FUSE_WAVES")) : 0;
     if (waves_env > 0 && waves_env < waves) waves = waves_env;
-    // (tried for fans of few waves: smaller workgroups so that every CU gets one -- 65 536 rays of 100 000 steps: the kernel
-    // 194 -> 155 ms, but the side rays' stored cast beside it, which then shares its CUs, 91 -> 215 ms: slower overall)
+    // fans of few waves: smaller workgroups, so that every CU gets one and every wave a SIMD of its own (65 536 rays of
+    // 100 000 steps: 194 -> 155 ms).  The workgroups then hold most of the LDS of every CU: a stored cast that is to run
+    // beside this kernel (the side rays) must be launched with RT2D_LAUNCH_SMALL_LDS, or it waits for this kernel to end.
+    while (waves > 1 && (n + (int64_t)waves * RT2D_WAVE - 1) / ((int64_t)waves * RT2D_WAVE) < env->n_cu) waves /= 2;
     const int block = waves * RT2D_WAVE;
     const size_t lds = cold + tab_bytes + (size_t)waves * per_wave;
     const int64_t grid = (n + block - 1) / block;

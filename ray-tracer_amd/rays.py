@@ -190,6 +190,7 @@ class RayFan:
         if self.target is not None:
             p.target[:] = [float(self.target[0]), float(self.target[1])]
         p.rebound_cap = int(rebound_cap)
+        p.launch_hint = int(self.__dict__.get('launch_hint', 0))
         p.power_cutoff, p.cutoff_freq = float(self.kw['power_cutoff']), float(self.kw['cutoff_freq'])
         return p
 
@@ -736,6 +737,8 @@ class RayFan:
                 if long_rays:
                     side = self.subset(part)
                     side.target, side.dist, side.step_target, side.T_target = None, None, None, None
+                    if after is not None and side_stream is not main:
+                        side.launch_hint = 1             # RT2D_LAUNCH_SMALL_LDS: beside the fused kernel, whose workgroups fill the LDS
                     side._need_store()
                 else:
                     init = None if self._init[0] is None else (self._init[0][part].cpu().numpy(), self._init[1][part].cpu().numpy())

@@ -85,6 +85,14 @@ def main():
             return fan, hm
         finally:
             rays_mod.CHUNKED_MIN_RAYS, = old
+    def count_only():
+        sim = rt.Simulation2D(env, source)
+        fan = sim.cast(angles, store=False)
+        fan.validate()
+        return fan
+    t_count, _ = timed(count_only, args.reps)
+    print(json.dumps({'count_pass_s': t_count}), flush=True)
+    res['count_pass_s'] = t_count
     ref = None
     for path in args.paths.split(','):
         t, (fan, hm) = timed(lambda: run(path), args.reps)

@@ -27,6 +27,8 @@ if len(sys.argv) > 3:      # python tools/wave_steps.py N lo hi [n_steps_max n_r
     angles = -np.linspace(float(sys.argv[2]), float(sys.argv[3]), n)
     if len(sys.argv) > 5:
         prop.update(n_steps_max=int(sys.argv[4]), n_rebounds_max=int(sys.argv[5]))
+    if len(sys.argv) > 7:  # ... dx_max dz_max
+        prop.update(dx_max=float(sys.argv[6]), dz_max=float(sys.argv[7]))
     kw = dict(target=np.array([30000., -300.]), store=False)
 source = np.array([0., 0.])
 fan = rt.RayFan(env, source, angles, **prop, **kw)
@@ -48,5 +50,6 @@ for w in list(order[:8]) + list(order[len(order) // 2: len(order) // 2 + 3]):
     print(f'{w:5d} {dur[w]:7.0f} {nt:11d} {ng:13d} {tt:9.0f} {tg:11.0f} {1e3 * tt / max(nt, 1):13.0f} {1e3 * tg / max(ng, 1):15.0f} {lg[w, 10]:8d} {lg[w, 11]:8d}')
 nt, ng, tt, tg = lg[:, 4].sum(), lg[:, 5].sum(), lg[:, 6].sum() / 100., lg[:, 7].sum() / 100.
 print(f'tight loop, shader clocks per step: head (update, guesses, LDS, decision) {lg[:, 8].sum() / max(nt, 1):.0f}, tail (commit, division) {lg[:, 9].sum() / max(nt, 1):.0f}')
+print(f'rebounds logged by the fan: {int(fan.n_rebounds.sum().item())} ({float(fan.n_rebounds.float().mean().item()):.1f} per ray)')
 print(f'all waves: {nt} tight steps in {tt:.0f} wave-us ({1e3 * tt / nt:.0f} ns each), {ng} general iterations in {tg:.0f} wave-us ({1e3 * tg / ng:.0f} ns each)')
 
