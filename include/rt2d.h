@@ -339,11 +339,16 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
  * a cell do not depend on the frequency, so they are worked out once and only the deposited value differs per map.
  * Gs: device array of n_freqs device pointers, each one frequency's gain in tile layout (rt2d_gain).  H: device,
  * n_freqs maps of nx*nz doubles one after the other, accumulated into (caller zeroes them).  Everything else as for
- * rt2d_heatmap_accumulate (ray_mask with its hint bits, work, n_dropped: counted once, not per map). */
+ * rt2d_heatmap_accumulate (ray_mask with its hint bits, work, n_dropped: counted once, not per map).
+ * H_minor: optional device scratch of 4 * ceil(n_freqs / 4) * nx*nz doubles (contents irrelevant on entry, garbage on
+ * return), or NULL.  With it the tile kernel deposits into a map-minor copy [group of 4 maps][cell][4] -- one L2 atomic
+ * request then carries a run's deposit for four maps (the L2s are bound by requests, not by the doubles in them) -- which
+ * is added into H before the call's remaining launches; without it every (run, map) pair is a request of its own.  Same maps
+ * up to the order of the sums. */
 int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const double* const* Gs, int32_t n_freqs,
                                       const int64_t* tile_off, const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                       const int32_t* res, const int32_t* shape,
-                                      double* H, int64_t* n_dropped, int32_t* work, void* stream);
+                                      double* H, int64_t* n_dropped, int32_t* work, double* H_minor, void* stream);
 
 /* rt2d_heatmap_finalize for n_maps maps stored one after the other (H and out), each normalised by its own maximum
  * (reference: simulation.py:133-138 per map).  scratch: device, at least 2 * n_maps doubles. */

@@ -171,7 +171,7 @@ def lib():
         'rt2d_target_products': [vp, vp, vp, vp, vp, vp, vp, vp, i64, C.POINTER(dbl), vp, i32, vp, vp, vp, vp],
         'rt2d_heatmap_accumulate': [vp, vp, vp, vp, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp],
         'rt2d_heatmap_accumulate_noalloc': [vp, vp, vp, vp, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp],
-        'rt2d_heatmap_accumulate_multi': [vp, vp, vp, i32, vp, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp],
+        'rt2d_heatmap_accumulate_multi': [vp, vp, vp, i32, vp, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp, vp],
         'rt2d_heatmap_finalize_multi': [vp, C.POINTER(i32), i32, dbl, dbl, vp, vp, vp],
         'rt2d_heatmap_finalize': [vp, C.POINTER(i32), dbl, dbl, vp, vp, vp],
         'rt2d_gain_heatmap': [vp, vp, vp, vp, vp, C.POINTER(Rt2dRayOut), i32, i64, dbl, vp, C.POINTER(i32), C.POINTER(i32),

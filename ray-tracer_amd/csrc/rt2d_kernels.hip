@@ -2419,6 +2419,8 @@ struct HeatArgs {
     const int32_t* g_slot; int64_t g_room;          // optional: G in the compact form of GainArgs::g_slot (general kernel only)
     int32_t group;                                  // general kernel: consecutive rays one workgroup bins, one after the other
     int32_t acc_cap;                                // ... slots of the LDS table their deposits are summed in (0 = none), power of two
+    double* H_minor;                                // several maps per pass, map-minor scratch: group g of FB maps at H_minor + g * map_stride * FB,
+                                                    // cell c of map k of the group at [c * FB + k] (see MINOR in rt2d_heatmap_fast_kernel)
 };
 
 // Fast path: one wave = one 64-ray tile, coalesced over the tile layout.  A ray whose cell column index never
@@ -2436,7 +2438,12 @@ struct HeatArgs {
 #ifndef HM_STAGE_ROWS
 #define HM_STAGE_ROWS 16     // rows of the walk between two flushes of it (a multiple of HM_UNROLL)
 #endif
-template <int MW, int FB>     // MW: 64-bit mask words per lane (rows nz <= 64 * MW); FB: maps (frequencies) binned per pass
+// MINOR (FB > 1): the deposits go to a map-minor scratch H_minor[group][cell][FB] instead of the maps.  The L2s take one atomic
+// REQUEST at a time whatever it carries (tools/probes/atomic_coalesce: 23.6 G requests/s with 1, 4 or 8 consecutive doubles
+// per request), and the FB sums of a run are FB consecutive doubles there: each wave queues its run sums in LDS (cell, FB
+// values: no hash, nothing is dropped or sent directly) and empties the queue with lanes laid out as (entry, map), so that
+// one request carries a run's deposit for all FB maps.  rt2d_hm_minor_add_kernel adds the scratch into the maps afterwards.
+template <int MW, int FB, bool MINOR = false>     // MW: 64-bit mask words per lane (rows nz <= 64 * MW); FB: maps (frequencies) binned per pass
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
     // FB > 1: blockIdx.y picks a group of FB frequencies.  The cells of a point, "first time this (column, row) is seen" and
     // the runs of equal cells across the wave are the same for every frequency: they are worked out once per point and
@@ -2466,7 +2473,9 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     __shared__ double s_stage_val[(FB > 1) ? 4 : 1][STAGE * FB];
     int32_t* const st_key = s_stage_key[(FB > 1) ? (threadIdx.x / RT2D_WAVE) : 0];
     double* const st_val = s_stage_val[(FB > 1) ? (threadIdx.x / RT2D_WAVE) : 0];
-    if (FB > 1) {
+    double* const Hmn = MINOR ? a.H_minor + (int64_t)blockIdx.y * a.map_stride * FB : nullptr;
+    int q_count = 0;                                                  // MINOR: entries in the wave's queue (wave-uniform)
+    if (FB > 1 && !MINOR) {
         for (int q = threadIdx.x & 63; q < STAGE; q += RT2D_WAVE) {
             st_key[q] = -1;
 #pragma unroll
@@ -2475,6 +2484,16 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     }
     auto stage_flush = [&]() {
         if (FB == 1) return;
+        if (MINOR) {
+            constexpr int SPW = RT2D_WAVE / FB;                        // queue entries per atomic instruction
+            const int ln = threadIdx.x & 63, kk = ln % FB, dq = ln / FB;
+            for (int q0 = 0; q0 < q_count; q0 += SPW) {
+                const int q = q0 + dq;
+                if (q < q_count && kk < nf) atomicAdd(&Hmn[(int64_t)st_key[q] * FB + kk], st_val[q * FB + kk]);
+            }
+            q_count = 0;
+            return;
+        }
         for (int q = threadIdx.x & 63; q < STAGE; q += RT2D_WAVE) {
             const int32_t key = st_key[q];
             if (key < 0) continue;
@@ -2632,7 +2651,12 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             // (FB > 1) the slot of the wave's staging table for this run's cell: claimed if free, shared if it is this cell's
             bool staged = false;
             int st_slot = 0;
-            if (FB > 1 && runs.tail) {
+            if (MINOR) {
+                const unsigned long long tmask = __ballot(runs.tail);
+                st_slot = q_count + __popcll(tmask & ((1ull << lane) - 1ull));
+                if (runs.tail) st_key[st_slot] = cell;
+                q_count += __popcll(tmask);
+            } else if (FB > 1 && runs.tail) {
                 st_slot = (int)(rt2d_hash32((uint32_t)cell) & (uint32_t)(STAGE - 1));
                 const int32_t old = atomicCAS(&st_key[st_slot], -1, cell);
                 staged = old == -1 || old == cell;
@@ -2649,12 +2673,14 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
                 }
                 const double v = runs.sum(val);
                 if (runs.tail) {
-                    if (FB > 1 && staged) unsafeAtomicAdd(&st_val[st_slot * FB + k], v);
+                    if (MINOR) st_val[st_slot * FB + k] = v;
+                    else if (FB > 1 && staged) unsafeAtomicAdd(&st_val[st_slot * FB + k], v);
                     else atomicAdd(&Hk[k][cell], v);
                 }
             }
+            if (MINOR && q_count > STAGE - RT2D_WAVE) stage_flush();              // (room for the next row's run sums)
         }
-        if (FB > 1 && (((row_hi - 1 - s0) / HM_UNROLL) % (HM_STAGE_ROWS / HM_UNROLL)) == (HM_STAGE_ROWS / HM_UNROLL) - 1) stage_flush();
+        if (!MINOR && FB > 1 && (((row_hi - 1 - s0) / HM_UNROLL) % (HM_STAGE_ROWS / HM_UNROLL)) == (HM_STAGE_ROWS / HM_UNROLL) - 1) stage_flush();
         // gains beyond +-3000 dB (a surface coefficient that underflowed to 0 at high frequency): the pow pair of the
         // reference, kept out of the loop above and present once in the program
         while (__builtin_expect(late != 0u, 0)) {
@@ -2666,10 +2692,21 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             for (int uu = 0; uu < HM_UNROLL; ++uu)
 #pragma unroll
                 for (int kk = 0; kk < FB; ++kk) if (u == uu && k == kk) { g = gs[uu][kk]; cell = late_cell[uu]; Hm = Hk[kk]; }
-            atomicAdd(&Hm[cell], rt2d_heat_val_pows(g));
+            if (MINOR) atomicAdd(&Hmn[(int64_t)cell * FB + k], rt2d_heat_val_pows(g));
+            else atomicAdd(&Hm[cell], rt2d_heat_val_pows(g));
         }
     }
     stage_flush();
+}
+
+// H[f][cell] += H_minor[f / fb][cell][f % fb] (see MINOR above); one thread per (map, cell), stream-ordered behind the tile
+// kernel: plain read-modify-write
+__global__ void __launch_bounds__(256) rt2d_hm_minor_add_kernel(const double* Hm, int64_t cells, int32_t n_freqs, int32_t fb, double* H) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (cell >= cells || f >= n_freqs) return;
+    const double v = Hm[((int64_t)(f / fb) * cells + cell) * fb + (f % fb)];
+    if (v != 0.0) H[(int64_t)f * cells + cell] += v;
 }
 
 // General path: one workgroup of HM_THREADS per ray, any trajectory.  The cell of every point is computed once into LDS
@@ -2683,6 +2720,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
 __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hash[];
     __shared__ int s_red[2];
+    __shared__ int2 s_own[HM_THREADS / RT2D_WAVE][RT2D_WAVE];      // (several maps through the map-minor scratch: a wave's owning points)
     int32_t* s_cell = reinterpret_cast<int32_t*>(s_hash + a.cap);
     // Neighbouring rays of the list visit mostly the same cells: a workgroup bins `group` consecutive rays one after the
     // other and sums their deposits in an LDS table first (acc_cap slots: cell -> sum, two probes, a deposit that finds
@@ -2822,6 +2860,33 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                             }
                         }
                         if (!staged) atomicAdd(&a.H[own[u]], v);
+                    }
+                } else if (a.H_minor) {
+                    // several maps, map-minor scratch (see MINOR in rt2d_heatmap_fast_kernel): the owning points of a wave are
+                    // compacted into LDS, then lanes are laid out as (owning point, map of a group of 4): one atomic request
+                    // carries a point's deposit for four maps, and every lane of the instruction has one to make
+                    constexpr int FBG = 4, SPW = RT2D_WAVE / FBG;
+                    int2* const own_q = s_own[lane >> 6];
+                    const int wl = lane & 63, kq = wl % FBG, dq = wl / FBG;
+                    const int n_groups = (a.n_freqs + FBG - 1) / FBG;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned long long om = __ballot(own[u] >= 0);
+                        if (om == 0ull) continue;
+                        const int c = __popcll(om);
+                        if (own[u] >= 0) own_q[__popcll(om & ((1ull << wl) - 1ull))] = make_int2(own[u], own_s[u]);
+                        for (int g = 0; g < n_groups; ++g) {
+                            const int f = g * FBG + kq;
+                            const double* Gf = a.Gs[min(f, a.n_freqs - 1)];
+                            double* Hg = a.H_minor + (int64_t)g * a.map_stride * FBG;
+                            for (int e0 = 0; e0 < c; e0 += SPW) {
+                                const int e = e0 + dq;
+                                if (e < c && f < a.n_freqs) {
+                                    const int2 q = own_q[e];
+                                    atomicAdd(&Hg[(int64_t)q.x * FBG + kq], rt2d_heat_val(Gf[base + (int64_t)q.y * RT2D_WAVE]));
+                                }
+                            }
+                        }
                     }
                 } else {
                     // several maps: the owning step of a cell is the same for every frequency, only the value differs
@@ -3872,7 +3937,7 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
                                        double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
                                        const double* const* Gs = nullptr, int32_t n_freqs = 0,
                                        const int32_t* rest_list = nullptr, int64_t n_rest = 0,
-                                       const int32_t* g_slot = nullptr, int64_t g_room = 0);
+                                       const int32_t* g_slot = nullptr, int64_t g_room = 0, double* H_minor = nullptr);
 }
 
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
@@ -3888,7 +3953,7 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
                                        const int32_t* res, const int32_t* shape,
                                        double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
                                        const double* const* Gs, int32_t n_freqs,
-                                       const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room) {
+                                       const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* H_minor) {
     if (!X || !Z || (!G && !Gs) || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
     if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
     if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
@@ -3943,6 +4008,11 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         return launch_general(n_rest, n_rest);
     }
     const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays && small_coords;
+    if (n_freqs > 0 && H_minor && !rest_list) {
+        // map-minor scratch (see MINOR in the tile kernel): zeroed here, filled by both kernels, added into the maps at the end
+        a.H_minor = H_minor;
+        HIP_OK(hipMemsetAsync(H_minor, 0, (size_t)((n_freqs + 3) / 4) * 4 * (size_t)a.map_stride * sizeof(double), stream));
+    }
     if (work && !fast) HIP_OK(hipMemsetAsync(work, 0xff, sizeof(int32_t), stream));     // work[0] = -1: every ray went general
     if (fast) {
         a.work = work;
@@ -3956,7 +4026,11 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         static const int wpb_env = getenv("RT2D_HM_WPB") ? atoi(getenv("RT2D_HM_WPB")) : 0;
         const int wpb = wpb_env > 0 ? wpb_env : ((n_waves <= 1024) ? 1 : 4);
         const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
-        if (n_freqs > 0) {
+        if (n_freqs > 0 && H_minor) {
+            const unsigned groups = (unsigned)((n_freqs + 3) / 4);
+            if (shape[1] <= 64) hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<1, 4, true>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
+            else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 4, true>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        } else if (n_freqs > 0) {
             const unsigned groups = (unsigned)((n_freqs + 3) / 4);
             if (shape[1] <= 64) hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<1, 4>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
             else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 4>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
@@ -3966,7 +4040,13 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     }
     // general kernel: everything (no workspace) or what the fast kernel queued (how many is only known on the device: a
     // few per cent of the fan as a rule); blocks stride over the items
-    return launch_general(fast ? n / 32 : n, n);
+    int32_t rc = launch_general(fast ? n / 32 : n, n);
+    if (!rc && a.H_minor) {
+        hipLaunchKernelGGL(rt2d_hm_minor_add_kernel, dim3((unsigned)((a.map_stride + 255) / 256), (unsigned)n_freqs), dim3(256), 0, stream,
+                           (const double*)H_minor, a.map_stride, n_freqs, 4, H);
+        HIP_OK(hipGetLastError());
+    }
+    return rc;
 }
 }  // extern "C++"
 
@@ -4016,10 +4096,11 @@ int32_t rt2d_heatmap_accumulate_noalloc(const double* X, const double* Z, const 
 int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const double* const* Gs, int32_t n_freqs,
                                       const int64_t* tile_off, const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                       const int32_t* res, const int32_t* shape,
-                                      double* H, int64_t* n_dropped, int32_t* work, void* stream) {
+                                      double* H, int64_t* n_dropped, int32_t* work, double* H_minor, void* stream) {
     if (!Gs) return fail("rt2d_heatmap_accumulate_multi: null argument");
     if (n_freqs <= 0) return n_freqs == 0 ? 0 : fail("rt2d_heatmap_accumulate_multi: negative frequency count");
-    return heatmap_accumulate_impl(X, Z, nullptr, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream, Gs, n_freqs);
+    return heatmap_accumulate_impl(X, Z, nullptr, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream, Gs, n_freqs,
+                                   nullptr, 0, nullptr, 0, H_minor);
 }
 
 // the library's own second stream per device (rt2d_gain_heatmap_rest), made on first use and kept

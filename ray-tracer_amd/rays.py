@@ -39,6 +39,7 @@ ONEPASS_MIN_ROWS, ONEPASS_ROWS_DIV = 4096, 8      # rows of the compact gain arr
 CHUNK_STREAMS = int(os.environ.get('RT2D_CHUNK_STREAMS', 2))
 MULTI_GROUP = int(os.environ.get('RT2D_MULTI_GROUP', 16))         # frequencies per group of heatmap_accumulate_multi's pipeline (0: off)
 MULTI_PIPELINE_MIN = 1 << 20                                      # rays x frequencies from which it is used
+MULTI_MINOR = os.environ.get('RT2D_MULTI_MINOR', '1') != '0'      # several maps per pass through the map-minor scratch (rt2d_heatmap_accumulate_multi)
 SIDE_STREAM = os.environ.get('RT2D_SIDE_STREAM', '1') != '0'      # side fans of the fused heat map on a second stream
 SIDE_FAN_RAYS = 1 << 16          # rays per stored side fan when the fused heat map hands rays to the stored path
 LOSS_WS_BYTES = int(os.environ.get('RT2D_LOSS_WS_BYTES', 4 << 30))      # rebound-loss workspace of rt2d_gain, at most
@@ -940,12 +941,20 @@ class RayFan:
             if self.n > HEATMAP_FAST_MIN_RAYS:
                 ray_mask = self.heatmap_mask(res, shape, ray_mask)
 
+            # scratch of the tile kernel's map-minor deposits (one allocation per call, reused by every group of maps: the
+            # groups are binned one after the other on this stream)
+            cells = int(shape[0]) * int(shape[1])
+            minor = None
+            if MULTI_MINOR and len(freqs) > 1:
+                minor = torch.empty((len(freqs) + 3) // 4 * 4 * cells, dtype=torch.float64, device=self.device)
+
             def bin_maps(k0, k1):
                 ptrs = torch.tensor([self.G[f].data_ptr() for f in freqs[k0:k1]], dtype=torch.int64, device=self.device)
+                use_minor = minor if minor is not None and ((k1 - k0 + 3) // 4 * 4 * cells) <= minor.numel() else None
                 _lib.check(L.rt2d_heatmap_accumulate_multi(self.X.data_ptr(), self.Z.data_ptr(), ptrs.data_ptr(), k1 - k0,
                                                            self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n, _ptr(ray_mask),
                                                            res_c, shape_c, H[k0:k1].data_ptr(), _ptr(dropped), work.data_ptr(),
-                                                           _raw_stream()))
+                                                           _ptr(use_minor), _raw_stream()))
 
             # Binning is bound by the f64 atomics of the L2s, the gain by vector issue and HBM: with many new frequencies on
             # a big fan the gain of the next group of frequencies runs on a second stream beside the binning of this one.
