@@ -177,7 +177,7 @@ def lib():
         'rt2d_gain_heatmap': [vp, vp, vp, vp, vp, C.POINTER(Rt2dRayOut), i32, i64, dbl, vp, C.POINTER(i32), C.POINTER(i32),
                               vp, vp, vp, vp, vp, vp, vp],
         'rt2d_gain_heatmap_rest': [vp, vp, vp, vp, vp, C.POINTER(Rt2dRayOut), i32, i64, dbl, vp, C.POINTER(i32), C.POINTER(i32),
-                                   vp, vp, i64, vp, i64, vp, vp, vp, vp, vp],
+                                   vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp],
         'rt2d_classify_rays': [vp, vp, vp, vp, vp, i64, C.POINTER(i32), C.POINTER(i32), i64, vp, vp, vp, vp, vp],
         'rt2d_cast_heatmap': [vp, vp, i64, C.POINTER(dbl), C.POINTER(Rt2dParams), vp, vp, vp, dbl, C.POINTER(i32),
                               C.POINTER(i32), dbl, vp, C.POINTER(Rt2dRayOut), vp, vp, vp, i32, vp],

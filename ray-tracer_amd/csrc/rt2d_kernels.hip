@@ -2443,6 +2443,8 @@ struct HeatArgs {
 // per request), and the FB sums of a run are FB consecutive doubles there: each wave queues its run sums in LDS (cell, FB
 // values: no hash, nothing is dropped or sent directly) and empties the queue with lanes laid out as (entry, map), so that
 // one request carries a run's deposit for all FB maps.  rt2d_hm_minor_add_kernel adds the scratch into the maps afterwards.
+// (Tried: the LDS summing the runs -- every lane of a run adds into its run's queue entry with ds_add_f64 instead of the DPP
+// scan per map: 64 maps x 65 536 rays 15.7 -> 17.3 ms for the maps.  Not kept.)
 template <int MW, int FB, bool MINOR = false>     // MW: 64-bit mask words per lane (rows nz <= 64 * MW); FB: maps (frequencies) binned per pass
 __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a) {
     // FB > 1: blockIdx.y picks a group of FB frequencies.  The cells of a point, "first time this (column, row) is seen" and
@@ -2930,6 +2932,7 @@ struct TailArgs {
     double freq; AlphaDesc ad; int32_t alpha_ok; int32_t pad;
     unsigned long long* scratch;                 // optional: the two words rt2d_hm_max_kernel accumulates into, cleared here
     double* overflow;                            // optional: set to 1 when a ray has more stored points than a workgroup holds
+    const int32_t* ray_list;                     // optional: [0] = number of rays (read on the device), [2 + k] = ray: only these, status and mask not consulted
     unsigned long long* dbg; int64_t dbg_cap;    // (RT2D_TAIL_LOG builds)
 };
 
@@ -2953,14 +2956,18 @@ __global__ void __launch_bounds__(TAIL_THREADS) rt2d_small_tail_kernel(const Tai
     // ray's 15 neighbours: workgroups go to the 8 XCDs round-robin, so rays are dealt in groups of 16 consecutive rays per
     // XCD and a line is fetched into ONE L2 (grid: a multiple of 128, as in rt2d_heatmap_kernel)
     const int64_t b_xcd = blockIdx.x & 7, b_in = blockIdx.x >> 3;
-    const int64_t r = ((b_in >> 4) * 8 + b_xcd) * 16 + (b_in & 15);
+    int64_t r = ((b_in >> 4) * 8 + b_xcd) * 16 + (b_in & 15);
     if (blockIdx.x == 0 && tid == 0 && t.scratch) { t.scratch[0] = 0ull; t.scratch[1] = 0ull; }
+    if (t.ray_list) {                                                       // (the side rays of rt2d_gain_heatmap_rest)
+        if (r >= (int64_t)t.ray_list[0]) return;
+        r = t.ray_list[2 + r];
+    }
     if (r >= a.n) return;
     // everything that depends on r alone is asked for at once (one global round trip instead of a chain of them): status,
     // mask, point count, the tile's bounds, the rebound count and -- whatever that count turns out to be -- this thread's
     // entry of the rebound log (an entry beyond the count is allocated, unspecified, and not used)
-    const int st = t.status[r];
-    const int mk = t.ray_mask ? (int)t.ray_mask[r] : 1;
+    const int st = t.ray_list ? 0 : t.status[r];
+    const int mk = (t.ray_mask && !t.ray_list) ? (int)t.ray_mask[r] : 1;
     const int np_raw = a.n_pts[r];
     const int64_t toff0 = a.tile_off[r >> 6], toff1 = a.tile_off[(r >> 6) + 1];
     const int nreb_raw = a.n_rebounds[r];
@@ -4125,11 +4132,41 @@ static int32_t rest_side(RestSide** out) {
 }
 }
 
+// The side rays of rt2d_gain_heatmap_rest by rt2d_small_tail_kernel in list mode: gain and binning of a ray by ONE workgroup
+// in ONE launch, no gain array (instead of the ray-sequential gain of the listed rays followed by the general binner).
+extern "C++" {
+static int32_t launch_tail_list(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
+                                const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const int32_t* res,
+                                const int32_t* shape, double* H, int64_t* n_dropped, const int32_t* rest_list, int64_t n_rest,
+                                double* overflow, hipStream_t stream) {
+    TailArgs t; memset(&t, 0, sizeof t);
+    GainArgs& a = t.g;
+    a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts;
+    a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
+    a.reb_velocity = reb->reb_velocity; a.reb_angle = reb->reb_angle; a.reb_pos_z = reb->reb_pos_z;
+    a.rebound_cap = rebound_cap; a.n = n; a.n_freqs = 1;
+    t.ray_list = rest_list;
+    t.geo.res_x = res[0]; t.geo.res_z = res[1]; t.geo.rx = res[0]; t.geo.rz = res[1];
+    t.geo.inv_rx = 1.0 / res[0]; t.geo.inv_rz = 1.0 / res[1];
+    t.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
+    t.nx = shape[0]; t.nz = shape[1]; t.H = H; t.n_dropped = n_dropped; t.freq = freq;
+    t.overflow = overflow;
+    static const int lean_env = getenv("RT2D_GH_LEAN") ? atoi(getenv("RT2D_GH_LEAN")) : 1;
+    bool ok = false;
+    if (lean_env) { int32_t rc = alpha_table_for(env, freq, &t.ad, &ok); if (rc) return rc; }
+    t.alpha_ok = ok ? 1 : 0;
+    const size_t lds = (size_t)(rebound_cap > 0 ? rebound_cap : 1) * 12 + 8;
+    hipLaunchKernelGGL(rt2d_small_tail_kernel, dim3((unsigned)((n_rest + 127) / 128 * 128)), dim3(TAIL_THREADS), lds, stream, t);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+}
+
 int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                                const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                                const int32_t* res, const int32_t* shape, double* H,
                                const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
-                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, void* stream) {
+                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, double* overflow, void* stream) {
     if (n_rest < 0 || (n_rest > 0 && (!rest_list || !g_slot || !G_rest || g_room <= 0)))
         return fail("rt2d_gain_heatmap_rest: rest_list, g_slot, G_rest and g_room describe the rays of ray_mask value 2");
     // the same argument checks as gain_heatmap_impl, BEFORE anything is dereferenced or queued on either stream
@@ -4174,10 +4211,22 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
     }
     HIP_OK(hipEventRecord(side->ready, main));
     HIP_OK(hipStreamWaitEvent(side->stream, side->ready, 0));
-    rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
-                           G_rest, nullptr, nullptr, nullptr, loss_ws, side->stream, g_slot, g_room, rest_list, n_rest, true);
-    if (!rc) rc = heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, side->stream,
-                                          nullptr, 0, rest_list, n_rest, g_slot, g_room);
+    // The side rays: one workgroup per ray does gain and binning in one launch when a ray fits a workgroup -- known (g_room
+    // bounds the stored points of a side ray) or watched (`overflow`: the kernel sets it for a longer ray, whose points are
+    // then missing from H, and the caller builds the map again the other way).  1 M-ray C2 fan, side chain beside the big
+    // pass: 3.9 + 3.0 ms (ray-sequential gain of the listed rays, then the general binner) -> one launch.
+    static const int tail_env = getenv("RT2D_REST_TAIL") ? atoi(getenv("RT2D_REST_TAIL")) : 1;
+    const bool by_tail = tail_env != 0 && (size_t)rebound_cap * 12 + 8 <= 15 * 1024 && (g_room <= TAIL_CAP || overflow != nullptr)
+                         && n_rest <= 0x7fffff00;
+    if (by_tail) {
+        rc = launch_tail_list(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, res, shape, H, n_dropped, rest_list, n_rest,
+                              g_room <= TAIL_CAP ? nullptr : overflow, side->stream);
+    } else {
+        rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
+                               G_rest, nullptr, nullptr, nullptr, loss_ws, side->stream, g_slot, g_room, rest_list, n_rest, true);
+        if (!rc) rc = heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, side->stream,
+                                              nullptr, 0, rest_list, n_rest, g_slot, g_room);
+    }
     if (!rc) rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
                                     nullptr, nullptr, nullptr, n_violations, loss_ws, stream, nullptr, 0, nullptr, 0, true);
     // (whatever happened above, the caller's stream must not run ahead of work already queued on the side stream)

@@ -86,6 +86,48 @@ def test_one_pass_map_queued_without_waiting_for_the_cast(rt, monkeypatch):
         assert (np.abs(Hx - Ha)[both] / np.abs(Ha[both])).max() < 1e-12
 
 
+def test_side_rays_of_the_one_pass_map_by_one_workgroup_each(rt, monkeypatch):
+    """The side rays of rt2d_gain_heatmap_rest (turned back, out of the map) are binned by one workgroup per ray in one launch
+    (rt2d_small_tail_kernel in list mode) when they fit a workgroup (2048 stored points).  Queued without waiting the host
+    only knows the room of the provisional layout: a side ray that turns out longer sets the word behind the fan's summary
+    and the map is built again by the waiting path (whose side rays, now known to be long, take the gain + general binner
+    chain).  Both ways against the three-kernel map."""
+    import torch
+    from ray_tracer_amd import rays
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    monkeypatch.setattr(rays, 'STREAM_MIN_RAYS', 100)
+
+    calls = []
+    real = rays.RayFan.heatmap_accumulate_stream
+
+    def logged(self, *args, **kwargs):
+        calls.append(bool(kwargs.get('defer', False)))
+        return real(self, *args, **kwargs)
+    monkeypatch.setattr(rays.RayFan, 'heatmap_accumulate_stream', logged)
+
+    def one(kw, **hk):
+        sim = rt.Simulation2D(env, g['fan_source'])
+        fan = sim.cast(g['fan_angles'], **kw)
+        pending = fan._pending
+        H, _ = sim.heatmap_full(resolution=[50, 25], **hk)
+        return fan, pending, H.cpu().numpy()
+
+    for kw, long_side in ((dict(dx_max=50., dz_max=25., n_rebounds_max=20), False),
+                          (dict(dx_max=20., dz_max=10., n_rebounds_max=20, n_steps_max=4000), True)):
+        fan_a, _, Ha = one(kw, stream=False)
+        del calls[:]
+        fan_b, pending, Hb = one(kw)
+        side = (fan_b.status == 0) & (fan_b.fused_mask([50, 25], Hb.shape, (fan_b.status == 0).to(torch.uint8)) == 0)
+        longest_side = int(fan_b.n_pts[side].max().item())
+        assert pending and int(side.sum().item()) > 0
+        assert (longest_side > 2048) == long_side
+        assert calls == ([True, False] if long_side else [True])     # (the kernel set the flag, read with the summary: start over)
+        assert Hb.shape == Ha.shape and np.array_equal(Hb == 0, Ha == 0)
+        both = np.isfinite(Ha) & (Ha != 0)
+        assert (np.abs(Hb - Ha)[both] / np.abs(Ha[both])).max() < 1e-12
+
+
 @pytest.mark.parametrize('name', ['c2_fan999', 'c3_bathy999', 't3_default10'])
 def test_alpha_table_is_verified_on_the_device(rt, name):
     """The binning-only pass reads -alpha(f, z) / 1000 from one degree-7 polynomial per depth piece (rt2d_onepass_kernel);
