@@ -271,14 +271,14 @@ int32_t rt2d_gain_heatmap(rt2d_env_t env, const double* X, const double* Z, cons
  * No gain array of the layout's size exists at any time.  Same map as rt2d_gain + rt2d_heatmap_accumulate.
  * When a listed ray is known to fit a workgroup (g_room <= 2048 stored points, rebound_cap <= 1279) the listed rays take a
  * shorter way: gain AND binning of a ray by one workgroup in one launch (the kernel of rt2d_small_fan_heatmap in list mode),
- * G_rest is not touched.  overflow (device double, may be NULL): lets them take it when g_room is only an upper bound above
- * 2048 -- a listed ray that turns out longer sets *overflow = 1 (never cleared here), its points are then MISSING from H and
- * the caller must build the map again with known sizes (RayFan does: the word behind the fan's summary). */
+ * G_rest is not touched.  rest_long (device, n_rest + 2 int32, contents irrelevant, may be NULL): lets them take it when g_room
+ * is larger -- the listed rays that turn out longer than a workgroup holds are collected there (same form as rest_list) and
+ * only those go through the compact array and the general kernel. */
 int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                                const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                                const int32_t* res, const int32_t* shape, double* H,
                                const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
-                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, double* overflow, void* stream);
+                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, int32_t* rest_long, void* stream);
 
 /* Diagnostic of the binning-only pass of rt2d_gain_heatmap / rt2d_gain_heatmap_rest (reference: the absorption of
  * ray.py:346 = model_absorption.py:19-46 at ONE frequency; no counterpart of the table itself).  When a launch stores no

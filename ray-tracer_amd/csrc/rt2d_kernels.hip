@@ -2933,6 +2933,7 @@ struct TailArgs {
     unsigned long long* scratch;                 // optional: the two words rt2d_hm_max_kernel accumulates into, cleared here
     double* overflow;                            // optional: set to 1 when a ray has more stored points than a workgroup holds
     const int32_t* ray_list;                     // optional: [0] = number of rays (read on the device), [2 + k] = ray: only these, status and mask not consulted
+    int32_t* long_list;                          // optional, same form: the rays with more stored points than a workgroup holds are appended instead of binned
     unsigned long long* dbg; int64_t dbg_cap;    // (RT2D_TAIL_LOG builds)
 };
 
@@ -2979,8 +2980,13 @@ __global__ void __launch_bounds__(TAIL_THREADS) rt2d_small_tail_kernel(const Tai
     if (st != 0 || mk == 0) return;                                         // (the same for the whole workgroup)
     const int np = (int)min((int64_t)np_raw, (toff1 - toff0) >> 6);         // rt2d_stored_pts
     if (np <= 0) return;
-    if (np > TAIL_CAP) {                                                    // the map will be incomplete: the caller is told and bins the fan another way
-        if (tid == 0 && t.overflow) *t.overflow = 1.0;
+    if (np > TAIL_CAP) {
+        if (tid == 0) {
+            if (t.long_list) {                                              // list mode: the ray is handed on (rt2d_gain_heatmap_rest bins these the other way)
+                const int k = atomicAdd(&t.long_list[0], 1);
+                t.long_list[2 + k] = (int32_t)r;
+            } else if (t.overflow) *t.overflow = 1.0;                       // the map will be incomplete: the caller is told and bins the fan another way
+        }
         return;
     }
     TAIL_STAMP(0)
@@ -4138,7 +4144,7 @@ extern "C++" {
 static int32_t launch_tail_list(rt2d_env_t env, const double* X, const double* Z, const int64_t* tile_off, const int32_t* n_pts,
                                 const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const int32_t* res,
                                 const int32_t* shape, double* H, int64_t* n_dropped, const int32_t* rest_list, int64_t n_rest,
-                                double* overflow, hipStream_t stream) {
+                                int32_t* long_list, hipStream_t stream) {
     TailArgs t; memset(&t, 0, sizeof t);
     GainArgs& a = t.g;
     a.env = env->dev; a.blob = env->blob; a.X = X; a.Z = Z; a.tile_off = tile_off; a.n_pts = n_pts;
@@ -4150,7 +4156,8 @@ static int32_t launch_tail_list(rt2d_env_t env, const double* X, const double* Z
     t.geo.inv_rx = 1.0 / res[0]; t.geo.inv_rz = 1.0 / res[1];
     t.geo.lim = (res[0] < (1 << 20) && res[1] < (1 << 20)) ? 2147483648.0 : 0.0;
     t.nx = shape[0]; t.nz = shape[1]; t.H = H; t.n_dropped = n_dropped; t.freq = freq;
-    t.overflow = overflow;
+    t.long_list = long_list;
+    if (long_list) HIP_OK(hipMemsetAsync(long_list, 0, 2 * sizeof(int32_t), stream));
     static const int lean_env = getenv("RT2D_GH_LEAN") ? atoi(getenv("RT2D_GH_LEAN")) : 1;
     bool ok = false;
     if (lean_env) { int32_t rc = alpha_table_for(env, freq, &t.ad, &ok); if (rc) return rc; }
@@ -4166,7 +4173,7 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
                                const Rt2dRayOut* reb, int32_t rebound_cap, int64_t n, double freq, const uint8_t* ray_mask,
                                const int32_t* res, const int32_t* shape, double* H,
                                const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* G_rest,
-                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, double* overflow, void* stream) {
+                               int64_t* n_dropped, int64_t* n_violations, double* loss_ws, int32_t* rest_long, void* stream) {
     if (n_rest < 0 || (n_rest > 0 && (!rest_list || !g_slot || !G_rest || g_room <= 0)))
         return fail("rt2d_gain_heatmap_rest: rest_list, g_slot, G_rest and g_room describe the rays of ray_mask value 2");
     // the same argument checks as gain_heatmap_impl, BEFORE anything is dereferenced or queued on either stream
@@ -4211,16 +4218,23 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
     }
     HIP_OK(hipEventRecord(side->ready, main));
     HIP_OK(hipStreamWaitEvent(side->stream, side->ready, 0));
-    // The side rays: one workgroup per ray does gain and binning in one launch when a ray fits a workgroup -- known (g_room
-    // bounds the stored points of a side ray) or watched (`overflow`: the kernel sets it for a longer ray, whose points are
-    // then missing from H, and the caller builds the map again the other way).  1 M-ray C2 fan, side chain beside the big
-    // pass: 3.9 + 3.0 ms (ray-sequential gain of the listed rays, then the general binner) -> one launch.
+    // The side rays: one workgroup per ray does gain and binning in one launch (rt2d_small_tail_kernel in list mode) when a
+    // ray fits a workgroup.  Known to (g_room bounds the stored points of a side ray), or sorted out by the kernel: a longer
+    // ray is appended to rest_long, and that list -- as a rule empty -- goes through the chain below.  1 M-ray C2 fan, side
+    // chain beside the big pass: 3.9 + 3.0 ms (ray-sequential gain of the listed rays, then the general binner) -> one launch.
     static const int tail_env = getenv("RT2D_REST_TAIL") ? atoi(getenv("RT2D_REST_TAIL")) : 1;
-    const bool by_tail = tail_env != 0 && (size_t)rebound_cap * 12 + 8 <= 15 * 1024 && (g_room <= TAIL_CAP || overflow != nullptr)
+    const bool by_tail = tail_env != 0 && (size_t)rebound_cap * 12 + 8 <= 15 * 1024 && (g_room <= TAIL_CAP || rest_long != nullptr)
                          && n_rest <= 0x7fffff00;
     if (by_tail) {
+        int32_t* const longer = g_room <= TAIL_CAP ? nullptr : rest_long;
         rc = launch_tail_list(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, res, shape, H, n_dropped, rest_list, n_rest,
-                              g_room <= TAIL_CAP ? nullptr : overflow, side->stream);
+                              longer, side->stream);
+        if (!rc && longer) {
+            rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
+                                   G_rest, nullptr, nullptr, nullptr, loss_ws, side->stream, g_slot, g_room, longer, n_rest, true);
+            if (!rc) rc = heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, side->stream,
+                                                  nullptr, 0, longer, n_rest, g_slot, g_room);
+        }
     } else {
         rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
                                G_rest, nullptr, nullptr, nullptr, loss_ws, side->stream, g_slot, g_room, rest_list, n_rest, true);

@@ -896,7 +896,7 @@ class RayFan:
                                                     self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(),
                                                     rest_list.data_ptr(), rows, slot.data_ptr(), g_room, G_rest.data_ptr(),
                                                     _ptr(dropped), viol.data_ptr(), _ptr(loss_ws),
-                                                    self._summary_dev[8:].data_ptr(), stream))
+                                                    torch.empty(rows + 2, dtype=torch.int32, device=self.device).data_ptr(), stream))
                 self._last_slow = rest_list            # ([0] = the number of side rays: read on demand)
                 self.last_fused_violations = viol
                 return
@@ -924,7 +924,8 @@ class RayFan:
                                                 self.tile_off.data_ptr(), self.n_pts.data_ptr(), C.byref(self._out), self.rebound_cap,
                                                 self.n, float(freq), m.data_ptr(), res_c, shape_c, H.data_ptr(),
                                                 rest_list.data_ptr(), n_rest, slot.data_ptr(), g_room, G_rest.data_ptr(),
-                                                _ptr(dropped), viol.data_ptr(), _ptr(loss_ws), None, stream))
+                                                _ptr(dropped), viol.data_ptr(), _ptr(loss_ws),
+                                                torch.empty(n_rest + 2, dtype=torch.int32, device=self.device).data_ptr(), stream))
             self.last_slow_rays = n_rest
             self.last_fused_violations = viol
 

@@ -89,9 +89,9 @@ def test_one_pass_map_queued_without_waiting_for_the_cast(rt, monkeypatch):
 def test_side_rays_of_the_one_pass_map_by_one_workgroup_each(rt, monkeypatch):
     """The side rays of rt2d_gain_heatmap_rest (turned back, out of the map) are binned by one workgroup per ray in one launch
     (rt2d_small_tail_kernel in list mode) when they fit a workgroup (2048 stored points).  Queued without waiting the host
-    only knows the room of the provisional layout: a side ray that turns out longer sets the word behind the fan's summary
-    and the map is built again by the waiting path (whose side rays, now known to be long, take the gain + general binner
-    chain).  Both ways against the three-kernel map."""
+    only knows the room of the provisional layout: the kernel collects the side rays that turn out longer in a second list
+    and only those take the gain + general binner chain -- nothing is read back, nothing built twice.  Both cases against
+    the three-kernel map."""
     import torch
     from ray_tracer_amd import rays
     g = common.load('c2_fan999')
@@ -122,7 +122,7 @@ def test_side_rays_of_the_one_pass_map_by_one_workgroup_each(rt, monkeypatch):
         longest_side = int(fan_b.n_pts[side].max().item())
         assert pending and int(side.sum().item()) > 0
         assert (longest_side > 2048) == long_side
-        assert calls == ([True, False] if long_side else [True])     # (the kernel set the flag, read with the summary: start over)
+        assert calls == [True]                                       # (queued once, not built again)
         assert Hb.shape == Ha.shape and np.array_equal(Hb == 0, Ha == 0)
         both = np.isfinite(Ha) & (Ha != 0)
         assert (np.abs(Hb - Ha)[both] / np.abs(Ha[both])).max() < 1e-12
