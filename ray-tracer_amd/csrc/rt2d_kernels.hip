@@ -4117,7 +4117,7 @@ int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const do
 }
 
 // the library's own second stream per device (rt2d_gain_heatmap_rest), made on first use and kept
-struct RestSide { hipStream_t stream; hipEvent_t ready, done; };
+struct RestSide { hipStream_t stream; hipEvent_t ready, losses, done; };
 extern "C++" {
 static int32_t rest_side(RestSide** out) {
     static std::mutex mu;
@@ -4130,6 +4130,7 @@ static int32_t rest_side(RestSide** out) {
     if (!made[dev]) {
         HIP_OK(hipStreamCreateWithFlags(&side[dev].stream, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&side[dev].ready, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&side[dev].losses, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&side[dev].done, hipEventDisableTiming));
         made[dev] = true;
     }
@@ -4206,6 +4207,9 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
     static std::mutex queue_mu;
     std::lock_guard<std::mutex> queue_lock(queue_mu);
     hipStream_t main = (hipStream_t)stream;
+    // (the one-workgroup-per-ray kernel works out the rebound losses of its ray itself: the side stream starts from HERE when
+    // it opens with that kernel, and only the chain that reads the loss table waits for the launch below)
+    HIP_OK(hipEventRecord(side->ready, main));
     {   // rebound losses, once, on the caller's stream (the same launch gain_heatmap_impl would make)
         GainArgs a; memset(&a, 0, sizeof a);
         a.env = env->dev; a.blob = env->blob; a.n_rebounds = reb->n_rebounds; a.reb_step = reb->reb_step; a.reb_surface = reb->reb_surface;
@@ -4216,8 +4220,7 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
             hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), 1u), dim3(256), 0, main, a, loss_ws, freq);
         HIP_OK(hipGetLastError());
     }
-    HIP_OK(hipEventRecord(side->ready, main));
-    HIP_OK(hipStreamWaitEvent(side->stream, side->ready, 0));
+    HIP_OK(hipEventRecord(side->losses, main));
     // The side rays: one workgroup per ray does gain and binning in one launch (rt2d_small_tail_kernel in list mode) when a
     // ray fits a workgroup.  Known to (g_room bounds the stored points of a side ray), or sorted out by the kernel: a longer
     // ray is appended to rest_long, and that list -- as a rule empty -- goes through the chain below.  1 M-ray C2 fan, side
@@ -4225,11 +4228,13 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
     static const int tail_env = getenv("RT2D_REST_TAIL") ? atoi(getenv("RT2D_REST_TAIL")) : 1;
     const bool by_tail = tail_env != 0 && (size_t)rebound_cap * 12 + 8 <= 15 * 1024 && (g_room <= TAIL_CAP || rest_long != nullptr)
                          && n_rest <= 0x7fffff00;
+    HIP_OK(hipStreamWaitEvent(side->stream, by_tail ? side->ready : side->losses, 0));
     if (by_tail) {
         int32_t* const longer = g_room <= TAIL_CAP ? nullptr : rest_long;
         rc = launch_tail_list(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, res, shape, H, n_dropped, rest_list, n_rest,
                               longer, side->stream);
         if (!rc && longer) {
+            HIP_OK(hipStreamWaitEvent(side->stream, side->losses, 0));
             rc = gain_heatmap_impl(env, X, Z, tile_off, n_pts, reb, rebound_cap, n, freq, ray_mask, res, shape, H,
                                    G_rest, nullptr, nullptr, nullptr, loss_ws, side->stream, g_slot, g_room, longer, n_rest, true);
             if (!rc) rc = heatmap_accumulate_impl(X, Z, G_rest, tile_off, n_pts, n, nullptr, res, shape, H, n_dropped, nullptr, side->stream,
