@@ -729,7 +729,7 @@ def main():
             '(rt2d_gain_heatmap_rest), nothing read back before the end', 'passes': fan_p2.passes,
             'max_abs_diff_vs_three_kernel_map': float((hm_p2 - hm_l).abs().max().item())}
         # the block's own figure is the product API's, like the headline's; the raw-ABI loop of three kernels (cast, gain,
-        # binning: the path of fans below 2^19 rays and the source of the per-stage times) is kept beside it
+        # binning: the path of fans below 2^17 rays and the source of the per-stage times) is kept beside it
         result['large_fan']['raw_abi_three_kernels'] = {'s_per_heatmap': result['large_fan']['s_per_heatmap'],
                                                         'value': result['large_fan']['value'], 'unit': 'ray-steps/s'}
         result['large_fan']['s_per_heatmap'] = dtp / args.large_steps

@@ -31,7 +31,7 @@ SPECULATIVE_BYTES = 1 << 30      # ... as long as the provisional X+Z stay below
 # (SPECULATIVE_ROOM points of room per ray) that is then kept as the fan's layout -- untouched pages cost nothing -- as
 # long as X+Z stay below this and a gain array still fits beside them; post() / several frequencies compact it first.
 PADDED_BYTES = int(os.environ.get('RT2D_PADDED_BYTES', 96 << 30))
-STREAM_MIN_RAYS = int(os.environ.get('RT2D_STREAM_MIN_RAYS', 1 << 19))    # fans from here on bin through the one-pass kernel
+STREAM_MIN_RAYS = int(os.environ.get('RT2D_STREAM_MIN_RAYS', 1 << 17))    # fans from here on bin through the one-pass kernel
 CHUNK_RAYS = int(os.environ.get('RT2D_CHUNK_RAYS', 0))               # rays cast with trajectories at a time by the chunked heat map;
                                                                      # 0: as many as a third of the free HBM holds (RayFan._chunk_rays)
 CHUNKED_MIN_RAYS = int(os.environ.get('RT2D_CHUNKED_MIN_RAYS', 1 << 18))   # store=False fans from here on use it (smaller: fused kernel)
