@@ -289,6 +289,13 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
  * table is in use (1) or not (0).  RT2D_GH_LEAN=0 in the environment switches the table and its kernel off altogether. */
 int32_t rt2d_alpha_table_error(rt2d_env_t env, double freq, double* max_rel_err, int32_t* in_use);
 
+/* The ray_mask of rt2d_heatmap_accumulate with its hint bits, made on the device from a cast's per-ray results (no reference
+ * counterpart; the reference bins every ray the same way, simulation.py:120-131): out[r] = 0 when ray_mask (may be NULL) leaves
+ * the ray out, else 1 | 2 when its x never decreases (monotone) and its bounding box (range, 4 x n as in Rt2dRayOut) lies
+ * inside the map of `shape` cells of `res` metres -- the tile kernel need not check such a ray point by point --, else 1 | 4. */
+int32_t rt2d_heatmap_hints(const uint8_t* monotone, const double* range, const uint8_t* ray_mask, int64_t n,
+                           const int32_t* res, const int32_t* shape, uint8_t* out, void* stream);
+
 /* The ray_mask, rest_list and g_slot arguments of rt2d_gain_heatmap_rest, made on the device from a cast's per-ray results
  * (no reference counterpart: RayFan.fused_mask, which it restates, needs the host to wait for the cast): m[r] = 1 / 2 / 0 as
  * described there for the rays with status 0 (and ray_mask != 0 when one is given); the rays of value 2 are appended to

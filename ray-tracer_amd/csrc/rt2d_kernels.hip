@@ -4254,6 +4254,30 @@ int32_t rt2d_gain_heatmap_rest(rt2d_env_t env, const double* X, const double* Z,
     return rc;
 }
 
+// ray_mask of rt2d_heatmap_accumulate with its hint bits, from a cast's per-ray results: 1 = bin this ray, | 2 = the caller
+// vouches that its x never decreases and its bounding box lies inside the map, | 4 = known not to qualify
+__global__ void __launch_bounds__(256) rt2d_heatmap_hints_kernel(const uint8_t* monotone, const double* range, const uint8_t* ray_mask,
+                                                                 int64_t n, double res_x, double res_z, double nx, double nz, uint8_t* out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const bool base = !ray_mask || ray_mask[r] != 0;
+    const bool good = base && monotone[r] != 0 && range[r] > -1 && range[3 * n + r] < 1
+                   && floor(trunc(range[2 * n + r]) / res_x) < nx && floor(-trunc(range[n + r]) / res_z) < nz;
+    out[r] = base ? (good ? 3 : 5) : 0;
+}
+
+int32_t rt2d_heatmap_hints(const uint8_t* monotone, const double* range, const uint8_t* ray_mask, int64_t n,
+                           const int32_t* res, const int32_t* shape, uint8_t* out, void* stream) {
+    if (!monotone || !range || !res || !shape || !out) return fail("rt2d_heatmap_hints: null argument");
+    if (n < 0) return fail("rt2d_heatmap_hints: negative ray count");
+    if (res[0] <= 0 || res[1] <= 0 || shape[0] <= 0 || shape[1] <= 0) return fail("rt2d_heatmap_hints: bad resolution or shape");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rt2d_heatmap_hints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, monotone, range,
+                       ray_mask, n, (double)res[0], (double)res[1], (double)shape[0], (double)shape[1], out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int32_t rt2d_classify_rays(const int32_t* status, const uint8_t* monotone, const double* range, const double* slope_max,
                            const uint8_t* ray_mask, int64_t n, const int32_t* res, const int32_t* shape, int64_t rows,
                            uint8_t* m, int32_t* g_slot, int32_t* rest_list, double* overflow, void* stream_) {

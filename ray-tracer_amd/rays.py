@@ -343,7 +343,7 @@ class RayFan:
                 cast_write(out, self.rebound_cap, off0, X0, Z0, C0)
                 make_views()                           # (the cast is running)
                 exact = torch.empty(n_tiles + 1, dtype=torch.int64, device=dev)
-                if n_tiles <= 1024:
+                if n_tiles <= 256:                   # (one workgroup does it all: 9 us for 999 rays, 107 us for 65 536)
                     # small fan: exact layout, summary and the mask of the error-free rays in ONE launch
                     self._summary_dev = torch.empty(SUMMARY_LEN, dtype=torch.float64, device=dev)
                     self._ok_mask = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -652,13 +652,14 @@ class RayFan:
         """ray_mask for rt2d_heatmap_accumulate with the hint bit (value 2) set for the rays whose x never decreases and
         whose bounding box lies inside the map: the tile kernel need not check those point by point."""
         torch = _torch()
-        rng = self.range
-        inside = ((rng[0] > -1) & (rng[3] < 1)                                  # int(x) >= 0, int(z) <= 0
-                  & (torch.div(torch.trunc(rng[2]), int(res[0]), rounding_mode='floor') < int(shape[0]))
-                  & (torch.div(-torch.trunc(rng[1]), int(res[1]), rounding_mode='floor') < int(shape[1])))
-        base = torch.ones(self.n, dtype=torch.uint8, device=self.device) if ray_mask is None else (ray_mask != 0).to(torch.uint8)
-        good = base * (inside & (self.monotone != 0)).to(torch.uint8)
-        return base + 2 * good + 4 * (base - good)          # 1 | 2: vouched for; 1 | 4: known not to qualify
+        # (one launch: int(x) >= 0, int(z) <= 0, last column and row inside the map, x never decreases -- a dozen torch
+        # kernels of 5 us each when written with tensor operations)
+        out = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().rt2d_heatmap_hints(self.monotone.data_ptr(), self.range.data_ptr(), _ptr(ray_mask), self.n,
+                                                     (C.c_int32 * 2)(int(res[0]), int(res[1])),
+                                                     (C.c_int32 * 2)(int(shape[0]), int(shape[1])), out.data_ptr(), _raw_stream()))
+        return out                                          # 1 | 2: vouched for; 1 | 4: known not to qualify
 
     def fused_mask(self, res, shape, ray_mask=None):
         """uint8 mask of the rays rt2d_cast_heatmap may bin (include/rt2d.h): no error, x never decreases, bounding box
