@@ -510,3 +510,59 @@ def test_gain_of_rays_with_thousands_of_rebounds(rt, orc):
             assert Gd[-1] == ge or (np.isneginf(Gd[-1]) and np.isneginf(ge))
     print(f'gain with the losses scattered into dG vs oracle: worst relative error {worst:.2e}')
     assert worst < 1e-10
+
+
+def test_hint_bits_and_the_map_minor_scratch(rt):
+    """Two helpers of the binning entry points through the C ABI.  rt2d_heatmap_hints (the hint bits of the ray mask in one
+    launch) against the same conditions written with tensor operations; rt2d_heatmap_accumulate_multi with and without its
+    map-minor scratch H_minor (one atomic request per run for four maps, added into the maps at the end): same maps to
+    1e-12, for a number of frequencies that is not a multiple of four, on a fan that uses both binning kernels."""
+    import ctypes as C
+    import torch
+    from ray_tracer_amd import rays
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    fan = rt.RayFan(env, g['fan_source'], -(np.arange(9000) + 1) * (0.999 / 9000), **common.prop_kwargs(g))
+    fan.validate()
+    L = rt._lib.lib()
+    res, shape = [50, 25], [1500, 61]
+    res_c, shape_c = (C.c_int32 * 2)(*res), (C.c_int32 * 2)(*shape)
+    stream = torch.cuda.current_stream().cuda_stream
+    keep = (torch.arange(fan.n, device='cuda') % 7 != 3).to(torch.uint8)
+    for mask in (None, keep):
+        out = torch.empty(fan.n, dtype=torch.uint8, device='cuda')
+        rt._lib.check(L.rt2d_heatmap_hints(fan.monotone.data_ptr(), fan.range.data_ptr(), rays._ptr(mask), fan.n, res_c, shape_c,
+                                           out.data_ptr(), stream))
+        rng = fan.range
+        inside = ((rng[0] > -1) & (rng[3] < 1)
+                  & (torch.div(torch.trunc(rng[2]), res[0], rounding_mode='floor') < shape[0])
+                  & (torch.div(-torch.trunc(rng[1]), res[1], rounding_mode='floor') < shape[1]))
+        base = torch.ones(fan.n, dtype=torch.uint8, device='cuda') if mask is None else (mask != 0).to(torch.uint8)
+        good = base * (inside & (fan.monotone != 0)).to(torch.uint8)
+        want = base + 2 * good + 4 * (base - good)
+        assert torch.equal(out, want)
+        assert int((out == 3).sum().item()) > 0 and int((out == 5).sum().item()) > 0
+    with pytest.raises(rt._lib.Rt2dError):
+        rt._lib.check(L.rt2d_heatmap_hints(None, fan.range.data_ptr(), None, fan.n, res_c, shape_c, out.data_ptr(), stream))
+
+    freqs = [1., 300., 1000., 5000., 20000.]
+    fan.populate(*freqs)
+    cells = shape[0] * shape[1]
+    ok = (fan.status == 0).to(torch.uint8)
+    hints = fan.heatmap_mask(res, shape, ok)
+    ptrs = torch.tensor([fan.G[f].data_ptr() for f in freqs], dtype=torch.int64, device='cuda')
+    maps = []
+    for use_minor in (False, True):
+        H = torch.zeros((len(freqs), cells), dtype=torch.float64, device='cuda')
+        work = torch.empty(fan.n + 2, dtype=torch.int32, device='cuda')
+        minor = torch.full((8 * cells,), float('nan'), dtype=torch.float64, device='cuda') if use_minor else None   # (contents irrelevant on entry)
+        rt._lib.check(L.rt2d_heatmap_accumulate_multi(fan.X.data_ptr(), fan.Z.data_ptr(), ptrs.data_ptr(), len(freqs),
+                                                      fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), fan.n, hints.data_ptr(),
+                                                      res_c, shape_c, H.data_ptr(), None, work.data_ptr(), rays._ptr(minor), stream))
+        assert int(work[0].item()) > 0                       # (rays went to the general kernel too)
+        maps.append(H.cpu().numpy())
+    a, b = maps
+    fin = np.isfinite(a)
+    assert np.array_equal(np.isfinite(b), fin) and np.array_equal(a == 0, b == 0)
+    m = fin & (a != 0)
+    assert (np.abs(a[m] - b[m]) / np.abs(a[m])).max() < 1e-12
