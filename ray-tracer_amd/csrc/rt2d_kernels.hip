@@ -495,12 +495,30 @@ __device__ __forceinline__ double rt2d_refcoef_sediment(double wavelength, doubl
 }
 
 // alpha(f, z) in dB/km from the six depth factors of one fused absorption record (model_absorption.py:37-44)
+// n / d, the IEEE quotient bit for bit for operands and quotients far from the ends of the exponent range: the compiler's
+// own sequence (v_rcp_f64, two Newton steps, the product, one residual correction) WITHOUT v_div_scale_f64 /
+// v_div_fmas_f64 / v_div_fixup_f64 around it, which leave such operands alone -- they rescale operands whose exponents
+// would make an intermediate overflow or go denormal, and patch up zeros, infinities and NaNs.  Three instructions and the
+// VCC dependence between them fewer per division; the callers guarantee the range (table values, squared frequencies,
+// sound speeds; the stepping kernel's tight loop votes on |k1| >= 1e-250 before it divides).  rt2d_debug_div_check counts
+// the operand pairs on which the two differ (tests/test_gpu_cast.py: none in 2^28 pairs over up to 200 decades, both signs,
+// numerators +0 included).  The one difference there is: a numerator of MINUS zero over a positive divisor gives +0 here
+// (the residual correction adds +0 to it), -0 by IEEE -- the sign of a zero that the callers either cannot produce
+// (positive numerators, voted |k1|) or add to a slope, where it changes nothing but the sign of a zero slope.
+__device__ __forceinline__ double rt2d_div_fast(double n, double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0); y = fma(y, e, y);
+    e = fma(-d, y, 1.0); y = fma(y, e, y);
+    const double q = n * y;
+    return fma(fma(-d, q, n), y, q);
+}
+
 __device__ __forceinline__ double rt2d_alpha(const double* rec, double d, double ff) {
     double f1 = rt2d_quad_of(rec, d, 0), f2 = rt2d_quad_of(rec, d, 1);
     double A2 = rt2d_quad_of(rec, d, 2), E1 = rt2d_quad_of(rec, d, 3);
     double E2 = rt2d_quad_of(rec, d, 4), E3 = rt2d_quad_of(rec, d, 5);
-    double alpha_1 = k_A1 * (f1 * ff) / (f1 * f1 + ff);
-    double alpha_2 = A2 * (f2 * ff) / (f2 * f2 + ff);
+    double alpha_1 = rt2d_div_fast(k_A1 * (f1 * ff), f1 * f1 + ff);     // model_absorption.py:37-44: the same quotients (rt2d_div_fast)
+    double alpha_2 = rt2d_div_fast(A2 * (f2 * ff), f2 * f2 + ff);
     double alpha_3 = k_A3 * ff;
     return alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
 }
@@ -509,13 +527,6 @@ __device__ __forceinline__ double rt2d_alpha(const double* rec, double d, double
 // 1e-12: FMA Horner, quotients and the square root to one ulp without the IEEE sequence's scaling and fix-up (the operands
 // are squares of table values plus (f/1000)^2 and squared distances in metres: no denormals, no overflow).  About 30
 // vector instructions fewer per point than the exact forms above, which every kernel that STORES a gain keeps.
-__device__ __forceinline__ double rt2d_div_fast(double n, double d) {
-    double y = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, y, 1.0); y = fma(y, e, y);
-    e = fma(-d, y, 1.0); y = fma(y, e, y);
-    const double q = n * y;
-    return fma(fma(-d, q, n), y, q);
-}
 __device__ __forceinline__ double rt2d_sqrt_fast(double a) {           // a >= 0
     const double y = __builtin_amdgcn_rsq(a);
     double g = a * y, h = 0.5 * y;
@@ -950,7 +961,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 auto examine = [&]() -> bool {
                     RT2D_WLOG(const unsigned long long c_a = __builtin_amdgcn_s_memtime();)
                     if (ST) {
-                        const double ss = p.dz_max / fabs(dx_z);                   // ray.py:153
+                        const double ss = rt2d_div_fast(p.dz_max, fabs(dx_z));     // ray.py:153 (the IEEE quotient: see rt2d_div_fast)
                         const bool st = fabs(dx_z) > dx_z_max;
                         steep_t = __builtin_amdgcn_ballot_w64(st);
                         const double sl = st ? ss : p.dx_max;
@@ -973,6 +984,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     zf_t = ta[1] * (xn - ta[0]) + ta[2];
                     unsigned long long ok_t = m_ge(xn, ta[0]) & m_lt(xn, ta[3]) & m_ge(zn, tz8[0]) & m_lt(zn, tz8[7]) & m_ge(zn, zf_t);
                     if (!ST) ok_t &= m_abs_ngt(dx_z, dx_z_max_v) & m_abs_ge(kz_s, 1e-250);
+                    else ok_t &= m_abs_ge(kz_s, 1e-250);              // (k1/k0 below without the IEEE sequence's scaling: normal operands only)
                     if (CEILC) {
                         ok_t &= m_le(zn, z_hi_bound);
                     } else {
@@ -1033,8 +1045,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     }
                     if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
                     const double k0 = cand ? o.rx : kx_s, k1 = cand ? o.rzz : kz_s;
-                    dx_z = k1 / k0;                                                       // ray.py:243
-                    const double dxdx_t = mult * dz_c_t / (c * c * c);
+                    dx_z = rt2d_div_fast(k1, k0);                                         // ray.py:243
+                    const double dxdx_t = rt2d_div_fast(mult * dz_c_t, c * c * c);
                     dx_z += dxdx_t * k0;
                     ++i;
                     return true;
@@ -1061,12 +1073,12 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                         if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
                         if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
                         if (ST) {
-                            dx_z = kz_s / kx_s;                                               // k1/k0 (ray.py:243)
+                            dx_z = rt2d_div_fast(kz_s, kx_s);                                 // k1/k0 (ray.py:243)
                         } else {
                             const double q_t = rt2d_div_by_const(kz_s, p.dx_max, a.inv_dx_max);
                             dx_z = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(q_t) ^ ((unsigned long long)flip << 32)));
                         }
-                        const double dxdx_t = mult * dz_c_t / (c * c * c);
+                        const double dxdx_t = rt2d_div_fast(mult * dz_c_t, c * c * c);
                         dx_z += dxdx_t * kx_s;
                         ++i;
                         RT2D_WLOG(asm volatile("" :: "v"(dx_z)); wave_log.clk_tail += __builtin_amdgcn_s_memtime() - c_b;)
@@ -1683,8 +1695,8 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < FCH; ++k) {
-            double alpha_1 = k_A1 * (f1 * ff[k]) / (f1s + ff[k]);          // model_absorption.py:37-44
-            double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
+            double alpha_1 = rt2d_div_fast(k_A1 * (f1 * ff[k]), f1s + ff[k]);          // model_absorption.py:37-44 (the IEEE quotients: rt2d_div_fast)
+            double alpha_2 = rt2d_div_fast(A2 * (f2 * ff[k]), f2s + ff[k]);
             double alpha_3 = k_A3 * ff[k];
             double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
             double dG = rt2d_div_1000(-1 * alpha) * dL;                            // ray.py:346
@@ -1745,8 +1757,8 @@ __global__ void __launch_bounds__(256) rt2d_gain_dg_kernel(const GainArgs a) {
         double f1s = f1 * f1, f2s = f2 * f2;
 #pragma unroll
         for (int k = 0; k < FCH; ++k) {
-            double alpha_1 = k_A1 * (f1 * ff[k]) / (f1s + ff[k]);          // model_absorption.py:37-44
-            double alpha_2 = A2 * (f2 * ff[k]) / (f2s + ff[k]);
+            double alpha_1 = rt2d_div_fast(k_A1 * (f1 * ff[k]), f1s + ff[k]);          // model_absorption.py:37-44 (the IEEE quotients: rt2d_div_fast)
+            double alpha_2 = rt2d_div_fast(A2 * (f2 * ff[k]), f2s + ff[k]);
             double alpha_3 = k_A3 * ff[k];
             double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
             double dG = rt2d_div_1000(-1 * alpha) * dL;                            // ray.py:346
@@ -3437,6 +3449,31 @@ static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const
     if (p->power_cutoff != p->power_cutoff) return fail("rt2d_cast: power_cutoff is NaN");
     if (p->power_cutoff > 0 && !(p->cutoff_freq > 0)) return fail("rt2d_cast: power_cutoff needs cutoff_freq > 0");
     return 0;
+}
+
+// development aid, not part of include/rt2d.h: on how many of n pseudo-random operand pairs (magnitudes log-uniform over
+// [10^lo10, 10^hi10], random signs, every 16th numerator +0) rt2d_div_fast and the compiler's IEEE division differ
+__global__ void __launch_bounds__(256) rt2d_div_check_kernel(int64_t n, uint64_t seed, double lo10, double hi10, unsigned long long* bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(i + 1);
+    auto next = [&]() { s ^= s >> 30; s *= 0xbf58476d1ce4e5b9ull; s ^= s >> 27; s *= 0x94d049bb133111ebull; s ^= s >> 31; return s; };
+    auto draw = [&]() {
+        const uint64_t u = next();
+        const double t = (double)(u >> 11) * (1.0 / 9007199254740992.0);
+        const double m = exp10(lo10 + (hi10 - lo10) * t) * (1.0 + (double)(next() >> 12) * (1.0 / 4503599627370496.0));
+        return (u & 1ull) ? -m : m;
+    };
+    double a = draw();
+    const double b = draw();
+    if ((i & 15) == 0) a = 0.0;
+    const double q_ieee = a / b, q_fast = rt2d_div_fast(a, b);
+    if (__double_as_longlong(q_ieee) != __double_as_longlong(q_fast)) atomicAdd(bad, 1ull);
+}
+int64_t rt2d_debug_div_check(int64_t n, uint64_t seed, double lo10, double hi10, unsigned long long* bad_dev, void* stream) {
+    if (n <= 0 || !bad_dev) return -1;
+    hipLaunchKernelGGL(rt2d_div_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, seed, lo10, hi10, bad_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // development aid, not part of include/rt2d.h: waves of the following cast launches log [start, end, hw id, xcc id]
