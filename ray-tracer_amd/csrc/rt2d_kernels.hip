@@ -513,6 +513,19 @@ __device__ __forceinline__ double rt2d_div_fast(double n, double d) {
     return fma(fma(-d, q, n), y, q);
 }
 
+// sqrt(a) likewise: the compiler's sequence (v_rsq_f64, one coupled Newton step for root and half reciprocal root, two
+// residual corrections) without the rescaling of tiny arguments and the class test around it; a = 0 handled by a select.
+// Same bits for normal a (rt2d_debug_div_check, mode 1).
+__device__ __forceinline__ double rt2d_sqrt_fast(double a) {           // a >= 0
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, a), h, g);
+    g = fma(fma(-g, g, a), h, g);
+    return a > 0.0 ? g : 0.0;
+}
+
 __device__ __forceinline__ double rt2d_alpha(const double* rec, double d, double ff) {
     double f1 = rt2d_quad_of(rec, d, 0), f2 = rt2d_quad_of(rec, d, 1);
     double A2 = rt2d_quad_of(rec, d, 2), E1 = rt2d_quad_of(rec, d, 3);
@@ -527,15 +540,6 @@ __device__ __forceinline__ double rt2d_alpha(const double* rec, double d, double
 // 1e-12: FMA Horner, quotients and the square root to one ulp without the IEEE sequence's scaling and fix-up (the operands
 // are squares of table values plus (f/1000)^2 and squared distances in metres: no denormals, no overflow).  About 30
 // vector instructions fewer per point than the exact forms above, which every kernel that STORES a gain keeps.
-__device__ __forceinline__ double rt2d_sqrt_fast(double a) {           // a >= 0
-    const double y = __builtin_amdgcn_rsq(a);
-    double g = a * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    g = fma(fma(-g, g, a), h, g);
-    g = fma(fma(-g, g, a), h, g);
-    return a > 0.0 ? g : 0.0;
-}
 __device__ __forceinline__ double rt2d_quad_fma(const double* r, double d, int k) {
     return fma(fma(r[1 + 3 * k], d, r[2 + 3 * k]), d, r[3 + 3 * k]);
 }
@@ -1023,8 +1027,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                     const double xa_t = cand ? o.xr : xn, za_t = cand ? o.z_hit : zn;
                     if (FULL) {
                         const double ddx = xa_t - x, ddz = za_t - z;
-                        const double dL = sqrt(ddx * ddx + ddz * ddz);
-                        L += dL; T += dL / c_pt;
+                        const double dL = rt2d_sqrt_fast(ddx * ddx + ddz * ddz);          // (the IEEE root and quotient: rt2d_sqrt_fast, rt2d_div_fast)
+                        L += dL; T += rt2d_div_fast(dL, c_pt);
                     }
                     if (cand) rebound_log(hitf, o, i + 1);
                     if (POST >= 1) mono &= !(xa_t < x);
@@ -1059,8 +1063,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                         if (POST >= 1) slope_max = vmax_abs(slope_max, dx_z);
                         if (FULL) {                                                       // ray.py:271-275
                             const double ddx = xn - x, ddz = zn - z;
-                            const double dL = sqrt(ddx * ddx + ddz * ddz);
-                            L += dL; T += dL / c_pt;
+                            const double dL = rt2d_sqrt_fast(ddx * ddx + ddz * ddz);
+                            L += dL; T += rt2d_div_fast(dL, c_pt);
                         }
                         x = xn; z = zn;
                         const double dzr_t = z - tz8[0];
@@ -3453,7 +3457,7 @@ static int32_t check_cast(rt2d_env_t env, const double* angles, int64_t n, const
 
 // development aid, not part of include/rt2d.h: on how many of n pseudo-random operand pairs (magnitudes log-uniform over
 // [10^lo10, 10^hi10], random signs, every 16th numerator +0) rt2d_div_fast and the compiler's IEEE division differ
-__global__ void __launch_bounds__(256) rt2d_div_check_kernel(int64_t n, uint64_t seed, double lo10, double hi10, unsigned long long* bad) {
+__global__ void __launch_bounds__(256) rt2d_div_check_kernel(int64_t n, uint64_t seed, double lo10, double hi10, unsigned long long* bad, int mode) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t s = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(i + 1);
@@ -3467,12 +3471,17 @@ __global__ void __launch_bounds__(256) rt2d_div_check_kernel(int64_t n, uint64_t
     double a = draw();
     const double b = draw();
     if ((i & 15) == 0) a = 0.0;
+    if (mode == 1) {                                                      // square roots of |b| (every 16th: of +0)
+        const double v = ((i & 15) == 0) ? 0.0 : fabs(b);
+        if (__double_as_longlong(sqrt(v)) != __double_as_longlong(rt2d_sqrt_fast(v))) atomicAdd(bad, 1ull);
+        return;
+    }
     const double q_ieee = a / b, q_fast = rt2d_div_fast(a, b);
     if (__double_as_longlong(q_ieee) != __double_as_longlong(q_fast)) atomicAdd(bad, 1ull);
 }
-int64_t rt2d_debug_div_check(int64_t n, uint64_t seed, double lo10, double hi10, unsigned long long* bad_dev, void* stream) {
+int64_t rt2d_debug_div_check(int64_t n, uint64_t seed, double lo10, double hi10, unsigned long long* bad_dev, int32_t mode, void* stream) {
     if (n <= 0 || !bad_dev) return -1;
-    hipLaunchKernelGGL(rt2d_div_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, seed, lo10, hi10, bad_dev);
+    hipLaunchKernelGGL(rt2d_div_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, seed, lo10, hi10, bad_dev, (int)mode);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
