@@ -353,8 +353,9 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
  * n_freqs maps of nx*nz doubles one after the other, accumulated into (caller zeroes them).  Everything else as for
  * rt2d_heatmap_accumulate (ray_mask with its hint bits, work, n_dropped: counted once, not per map).
  * H_minor: optional device scratch of 4 * ceil(n_freqs / 4) * nx*nz doubles (contents irrelevant on entry, garbage on
- * return), or NULL.  With it the tile kernel deposits into a map-minor copy [group of 4 maps][cell][4] -- one L2 atomic
- * request then carries a run's deposit for four maps (the L2s are bound by requests, not by the doubles in them) -- which
+ * return), or NULL.  With it both binning kernels deposit into a map-minor copy [group of 8 or 4 maps][cell][8 or 4] -- one
+ * L2 atomic request then carries a run's deposit for the maps of a group (the L2s are bound by requests, not by the doubles
+ * in them; groups of 8 when 8 * ceil(n_freqs / 8) doubles per cell fit this size, i.e. n_freqs mod 8 is 0 or above 4) -- which
  * is added into H before the call's remaining launches; without it every (run, map) pair is a request of its own.  Same maps
  * up to the order of the sums. */
 int32_t rt2d_heatmap_accumulate_multi(const double* X, const double* Z, const double* const* Gs, int32_t n_freqs,

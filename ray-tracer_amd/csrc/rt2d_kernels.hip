@@ -2435,6 +2435,7 @@ struct HeatArgs {
     const int32_t* g_slot; int64_t g_room;          // optional: G in the compact form of GainArgs::g_slot (general kernel only)
     int32_t group;                                  // general kernel: consecutive rays one workgroup bins, one after the other
     int32_t acc_cap;                                // ... slots of the LDS table their deposits are summed in (0 = none), power of two
+    int32_t minor_fb, pad_minor;                    // maps per group of the scratch below (4 or 8)
     double* H_minor;                                // several maps per pass, map-minor scratch: group g of FB maps at H_minor + g * map_stride * FB,
                                                     // cell c of map k of the group at [c * FB + k] (see MINOR in rt2d_heatmap_fast_kernel)
 };
@@ -2486,7 +2487,8 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     // sit in many cells at one step they have been scattered by a dozen rebounds and share cells with nobody.  Tried beyond
     // it: ONE table for four adjacent tiles per workgroup, flushed per window of 16 absolute rows between barriers: 252 M
     // atomics (-25 %) but 18.4 ms against 17.6 for the launch (the barriers), 0.645 ms per map: not kept.
-    constexpr int STAGE = (FB > 1) ? HM_STAGE : 1;
+    constexpr int STAGE = (FB >= 8) ? HM_STAGE / 2 : (FB > 1) ? HM_STAGE : 1;      // (8 maps: half the entries, the same LDS)
+    constexpr int UNR = (FB >= 8) ? 2 : HM_UNROLL;                                   // rows in flight per lane (8 maps: 2 x 10 loads)
     __shared__ int32_t s_stage_key[(FB > 1) ? 4 : 1][STAGE];
     __shared__ double s_stage_val[(FB > 1) ? 4 : 1][STAGE * FB];
     int32_t* const st_key = s_stage_key[(FB > 1) ? (threadIdx.x / RT2D_WAVE) : 0];
@@ -2630,10 +2632,10 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             }
         }
     }
-    for (int s0 = row_hi - 1; s0 >= row_lo; s0 -= HM_UNROLL) {
-        double xs[HM_UNROLL], zs[HM_UNROLL], gs[HM_UNROLL][FB];
+    for (int s0 = row_hi - 1; s0 >= row_lo; s0 -= UNR) {
+        double xs[UNR], zs[UNR], gs[UNR][FB];
 #pragma unroll
-        for (int u = 0; u < HM_UNROLL; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int64_t o = base + (int64_t)min(max(s0 - u, 0), last) * RT2D_WAVE;
             xs[u] = a.X[o];
             zs[u] = a.Z[o];
@@ -2641,9 +2643,9 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             for (int k = 0; k < FB; ++k) gs[u][k] = Gk[k][o];
         }
         unsigned late = 0u;                                 // (row, map) pairs of this batch whose value needs the two pows
-        int late_cell[HM_UNROLL];
+        int late_cell[UNR];
 #pragma unroll
-        for (int u = 0; u < HM_UNROLL; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int s = s0 - u;
             bool fresh = false;
             int cell = -1 - lane;                           // unique per lane: never merges
@@ -2698,7 +2700,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             }
             if (MINOR && q_count > STAGE - RT2D_WAVE) stage_flush();              // (room for the next row's run sums)
         }
-        if (!MINOR && FB > 1 && (((row_hi - 1 - s0) / HM_UNROLL) % (HM_STAGE_ROWS / HM_UNROLL)) == (HM_STAGE_ROWS / HM_UNROLL) - 1) stage_flush();
+        if (!MINOR && FB > 1 && (((row_hi - 1 - s0) / UNR) % (HM_STAGE_ROWS / UNR)) == (HM_STAGE_ROWS / UNR) - 1) stage_flush();
         // gains beyond +-3000 dB (a surface coefficient that underflowed to 0 at high frequency): the pow pair of the
         // reference, kept out of the loop above and present once in the program
         while (__builtin_expect(late != 0u, 0)) {
@@ -2707,7 +2709,7 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
             const int u = b / FB, k = b % FB;
             double g = gs[0][0]; int cell = late_cell[0]; double* Hm = Hk[0];
 #pragma unroll
-            for (int uu = 0; uu < HM_UNROLL; ++uu)
+            for (int uu = 0; uu < UNR; ++uu)
 #pragma unroll
                 for (int kk = 0; kk < FB; ++kk) if (u == uu && k == kk) { g = gs[uu][kk]; cell = late_cell[uu]; Hm = Hk[kk]; }
             if (MINOR) atomicAdd(&Hmn[(int64_t)cell * FB + k], rt2d_heat_val_pows(g));
@@ -2883,7 +2885,7 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                     // several maps, map-minor scratch (see MINOR in rt2d_heatmap_fast_kernel): the owning points of a wave are
                     // compacted into LDS, then lanes are laid out as (owning point, map of a group of 4): one atomic request
                     // carries a point's deposit for four maps, and every lane of the instruction has one to make
-                    constexpr int FBG = 4, SPW = RT2D_WAVE / FBG;
+                    const int FBG = a.minor_fb, SPW = RT2D_WAVE / FBG;      // 4 or 8 maps per group, as the scratch is laid out
                     int2* const own_q = s_own[lane >> 6];
                     const int wl = lane & 63, kq = wl % FBG, dq = wl / FBG;
                     const int n_groups = (a.n_freqs + FBG - 1) / FBG;
@@ -4069,6 +4071,10 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     const bool fast = work != nullptr && shape[1] <= 256 && n > fast_min_rays && small_coords;
     if (n_freqs > 0 && H_minor && !rest_list) {
         // map-minor scratch (see MINOR in the tile kernel): zeroed here, filled by both kernels, added into the maps at the end
+        // groups of 8 maps when that needs no more scratch than groups of 4 (the size the header asks for)
+        a.minor_fb = ((n_freqs + 7) / 8 * 8 == (n_freqs + 3) / 4 * 4) ? 8 : 4;
+        static const int fb_env = getenv("RT2D_MINOR_FB") ? atoi(getenv("RT2D_MINOR_FB")) : 0;      // experiments: 4
+        if (fb_env == 4) a.minor_fb = 4;
         a.H_minor = H_minor;
         HIP_OK(hipMemsetAsync(H_minor, 0, (size_t)((n_freqs + 3) / 4) * 4 * (size_t)a.map_stride * sizeof(double), stream));
     }
@@ -4085,7 +4091,11 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
         static const int wpb_env = getenv("RT2D_HM_WPB") ? atoi(getenv("RT2D_HM_WPB")) : 0;
         const int wpb = wpb_env > 0 ? wpb_env : ((n_waves <= 1024) ? 1 : 4);
         const unsigned blocks = (unsigned)((n_waves + wpb - 1) / wpb);
-        if (n_freqs > 0 && H_minor) {
+        if (n_freqs > 0 && H_minor && a.minor_fb == 8) {
+            const unsigned groups = (unsigned)((n_freqs + 7) / 8);
+            if (shape[1] <= 64) hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<1, 8, true>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
+            else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 8, true>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
+        } else if (n_freqs > 0 && H_minor) {
             const unsigned groups = (unsigned)((n_freqs + 3) / 4);
             if (shape[1] <= 64) hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<1, 4, true>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
             else hipLaunchKernelGGL((rt2d_heatmap_fast_kernel<4, 4, true>), dim3(blocks, groups), dim3(wpb * RT2D_WAVE), 0, stream, a);
@@ -4102,7 +4112,7 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     int32_t rc = launch_general(fast ? n / 32 : n, n);
     if (!rc && a.H_minor) {
         hipLaunchKernelGGL(rt2d_hm_minor_add_kernel, dim3((unsigned)((a.map_stride + 255) / 256), (unsigned)n_freqs), dim3(256), 0, stream,
-                           (const double*)H_minor, a.map_stride, n_freqs, 4, H);
+                           (const double*)H_minor, a.map_stride, n_freqs, a.minor_fb, H);
         HIP_OK(hipGetLastError());
     }
     return rc;

@@ -550,19 +550,20 @@ def test_hint_bits_and_the_map_minor_scratch(rt):
     cells = shape[0] * shape[1]
     ok = (fan.status == 0).to(torch.uint8)
     hints = fan.heatmap_mask(res, shape, ok)
-    ptrs = torch.tensor([fan.G[f].data_ptr() for f in freqs], dtype=torch.int64, device='cuda')
-    maps = []
-    for use_minor in (False, True):
-        H = torch.zeros((len(freqs), cells), dtype=torch.float64, device='cuda')
-        work = torch.empty(fan.n + 2, dtype=torch.int32, device='cuda')
-        minor = torch.full((8 * cells,), float('nan'), dtype=torch.float64, device='cuda') if use_minor else None   # (contents irrelevant on entry)
-        rt._lib.check(L.rt2d_heatmap_accumulate_multi(fan.X.data_ptr(), fan.Z.data_ptr(), ptrs.data_ptr(), len(freqs),
-                                                      fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), fan.n, hints.data_ptr(),
-                                                      res_c, shape_c, H.data_ptr(), None, work.data_ptr(), rays._ptr(minor), stream))
-        assert int(work[0].item()) > 0                       # (rays went to the general kernel too)
-        maps.append(H.cpu().numpy())
-    a, b = maps
-    fin = np.isfinite(a)
-    assert np.array_equal(np.isfinite(b), fin) and np.array_equal(a == 0, b == 0)
-    m = fin & (a != 0)
-    assert (np.abs(a[m] - b[m]) / np.abs(a[m])).max() < 1e-12
+    for nf in (5, 4):                                        # (groups of eight maps in the scratch; groups of four)
+        ptrs = torch.tensor([fan.G[f].data_ptr() for f in freqs[:nf]], dtype=torch.int64, device='cuda')
+        maps = []
+        for use_minor in (False, True):
+            H = torch.zeros((nf, cells), dtype=torch.float64, device='cuda')
+            work = torch.empty(fan.n + 2, dtype=torch.int32, device='cuda')
+            minor = torch.full(((nf + 3) // 4 * 4 * cells,), float('nan'), dtype=torch.float64, device='cuda') if use_minor else None   # (contents irrelevant on entry)
+            rt._lib.check(L.rt2d_heatmap_accumulate_multi(fan.X.data_ptr(), fan.Z.data_ptr(), ptrs.data_ptr(), nf,
+                                                          fan.tile_off.data_ptr(), fan.n_pts.data_ptr(), fan.n, hints.data_ptr(),
+                                                          res_c, shape_c, H.data_ptr(), None, work.data_ptr(), rays._ptr(minor), stream))
+            assert int(work[0].item()) > 0                   # (rays went to the general kernel too)
+            maps.append(H.cpu().numpy())
+        a, b = maps
+        fin = np.isfinite(a)
+        assert np.array_equal(np.isfinite(b), fin) and np.array_equal(a == 0, b == 0)
+        m = fin & (a != 0)
+        assert (np.abs(a[m] - b[m]) / np.abs(a[m])).max() < 1e-12
