@@ -37,7 +37,7 @@ CHUNK_RAYS = int(os.environ.get('RT2D_CHUNK_RAYS', 0))               # rays cast
 CHUNKED_MIN_RAYS = int(os.environ.get('RT2D_CHUNKED_MIN_RAYS', 1 << 18))   # store=False fans from here on use it (smaller: fused kernel)
 ONEPASS_MIN_ROWS, ONEPASS_ROWS_DIV = 4096, 8      # rows of the compact gain array of a one-pass map queued without waiting: max(.., n / ..)
 CHUNK_STREAMS = int(os.environ.get('RT2D_CHUNK_STREAMS', 2))
-MULTI_GROUP = int(os.environ.get('RT2D_MULTI_GROUP', 16))         # frequencies per group of heatmap_accumulate_multi's pipeline (0: off)
+MULTI_GROUP = int(os.environ.get('RT2D_MULTI_GROUP', 32))         # frequencies per group of heatmap_accumulate_multi's pipeline (0: off)
 MULTI_PIPELINE_MIN = 1 << 20                                      # rays x frequencies from which it is used
 MULTI_MINOR = os.environ.get('RT2D_MULTI_MINOR', '1') != '0'      # several maps per pass through the map-minor scratch (rt2d_heatmap_accumulate_multi)
 SIDE_STREAM = os.environ.get('RT2D_SIDE_STREAM', '1') != '0'      # side fans of the fused heat map on a second stream
