@@ -3383,6 +3383,15 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
         static const int lanes_env = getenv("RT2D_CAST_LANES") ? atoi(getenv("RT2D_CAST_LANES")) : 0;
         // (measured on the refine cones, 4590 near-vertical rays of up to 100 000 steps: 669 / 800 / 891 ms per three
         // iterations with 32 / 16 / 8 rays per wave -- co-resident waves cost more than shared rebound branches)
+        // More than 16 rays per CU: 16 rays per wave and up to four waves per CU (one per SIMD) -- a wave runs the rebound
+        // branch whenever any of its rays rebounds, and with a bounded rebound count the shorter waves pay for the
+        // company: stored casts at dx_max 50 / dz_max 25, 20 rebounds, 6000 / 12 288 / 16 384 rays 1.03 -> 0.94, 1.27 -> 0.88,
+        // 1.24 -> 0.89 ms (8192: 0.99 either way; 8 rays per wave: slower again).  Not without a rebound limit: rays that
+        // rebound every few steps keep the LDS busy, and the refine cones (4590 rays) took 669 / 800 ms at 32 / 16 per wave.
+        if (lanes > 16 && lanes_env == 0 && a.p.n_rebounds_max >= 0 && !hybrid && in_lds) {
+            block = (lanes / 16) * RT2D_WAVE;
+            a.lanes = lanes = 16;
+        }
         if (lanes_env >= 1 && lanes_env < lanes && (lanes_env & (lanes_env - 1)) == 0 &&
             (lanes / lanes_env) <= (hybrid || !in_lds ? 16 : RT2D_TAB1_MAX_WAVES)) {          // within the instance's launch bound
             block = (lanes / lanes_env) * RT2D_WAVE;
