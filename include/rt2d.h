@@ -346,6 +346,15 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
                                 const int32_t* res, const int32_t* shape,
                                 double* H, int64_t* n_dropped, int32_t* work, void* stream);
 
+/* rt2d_heatmap_accumulate with one more piece of knowledge: max_pts, an upper bound of the stored points of any binned ray
+ * (0 = unknown: then exactly rt2d_heatmap_accumulate).  Rays of tens of thousands of points -- the reference's default step
+ * sizes, preferences.py:6-9 -- get a larger hash in the one-ray-per-workgroup kernel, which otherwise walks such a ray once
+ * per partition of its candidate cells.  Same map. */
+int32_t rt2d_heatmap_accumulate_hinted(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                       const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                       const int32_t* res, const int32_t* shape,
+                                       double* H, int64_t* n_dropped, int32_t* work, int64_t max_pts, void* stream);
+
 /* Heat maps of n_freqs frequencies in ONE pass over the trajectories (reference: the frequency loop of populate_NEW,
  * ray.py:345-362, followed by simulation.py:120-131 once per frequency): the cell of a point and which point of a ray owns
  * a cell do not depend on the frequency, so they are worked out once and only the deposited value differs per map.

@@ -19,7 +19,7 @@ RAY_OK, RAY_ERR_INTERP, RAY_ERR_REBOUND_LOG = 0, -1, -2
 
 EXPORTS = ['rt2d_last_error', 'rt2d_version', 'rt2d_env_create', 'rt2d_env_destroy', 'rt2d_env_surface_speed',
            'rt2d_cast_count', 'rt2d_traj_layout', 'rt2d_fan_summary', 'rt2d_cast_write', 'rt2d_traj_compact', 'rt2d_post', 'rt2d_gain', 'rt2d_dist', 'rt2d_target_products',
-           'rt2d_heatmap_accumulate', 'rt2d_heatmap_accumulate_noalloc', 'rt2d_heatmap_accumulate_multi', 'rt2d_heatmap_finalize_multi', 'rt2d_heatmap_finalize', 'rt2d_cast_heatmap', 'rt2d_gain_heatmap', 'rt2d_gain_heatmap_rest', 'rt2d_classify_rays', 'rt2d_layout_summary', 'rt2d_rebound_loss', 'rt2d_alpha_table_error', 'rt2d_small_fan_heatmap', 'rt2d_heatmap_hints']
+           'rt2d_heatmap_accumulate', 'rt2d_heatmap_accumulate_noalloc', 'rt2d_heatmap_accumulate_multi', 'rt2d_heatmap_finalize_multi', 'rt2d_heatmap_finalize', 'rt2d_cast_heatmap', 'rt2d_gain_heatmap', 'rt2d_gain_heatmap_rest', 'rt2d_classify_rays', 'rt2d_layout_summary', 'rt2d_rebound_loss', 'rt2d_alpha_table_error', 'rt2d_small_fan_heatmap', 'rt2d_heatmap_hints', 'rt2d_heatmap_accumulate_hinted']
 
 
 def source_hash():
@@ -180,6 +180,7 @@ def lib():
                                    vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp],
         'rt2d_classify_rays': [vp, vp, vp, vp, vp, i64, C.POINTER(i32), C.POINTER(i32), i64, vp, vp, vp, vp, vp],
         'rt2d_heatmap_hints': [vp, vp, vp, i64, C.POINTER(i32), C.POINTER(i32), vp, vp],
+        'rt2d_heatmap_accumulate_hinted': [vp, vp, vp, vp, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, i64, vp],
         'rt2d_cast_heatmap': [vp, vp, i64, C.POINTER(dbl), C.POINTER(Rt2dParams), vp, vp, vp, dbl, C.POINTER(i32),
                               C.POINTER(i32), dbl, vp, C.POINTER(Rt2dRayOut), vp, vp, vp, i32, vp],
         'rt2d_rebound_loss': [vp, C.POINTER(Rt2dRayOut), i32, i64, vp, i32, vp, vp],

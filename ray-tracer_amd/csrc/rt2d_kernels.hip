@@ -4014,7 +4014,8 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
                                        double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
                                        const double* const* Gs = nullptr, int32_t n_freqs = 0,
                                        const int32_t* rest_list = nullptr, int64_t n_rest = 0,
-                                       const int32_t* g_slot = nullptr, int64_t g_room = 0, double* H_minor = nullptr);
+                                       const int32_t* g_slot = nullptr, int64_t g_room = 0, double* H_minor = nullptr,
+                                       int64_t max_pts = 0);
 }
 
 int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* G, const int64_t* tile_off,
@@ -4024,13 +4025,23 @@ int32_t rt2d_heatmap_accumulate(const double* X, const double* Z, const double* 
     return heatmap_accumulate_impl(X, Z, G, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream_);
 }
 
+int32_t rt2d_heatmap_accumulate_hinted(const double* X, const double* Z, const double* G, const int64_t* tile_off,
+                                       const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
+                                       const int32_t* res, const int32_t* shape,
+                                       double* H, int64_t* n_dropped, int32_t* work, int64_t max_pts, void* stream_) {
+    if (max_pts < 0) return fail("rt2d_heatmap_accumulate_hinted: negative max_pts");
+    return heatmap_accumulate_impl(X, Z, G, tile_off, n_pts, n, ray_mask, res, shape, H, n_dropped, work, (hipStream_t)stream_,
+                                   nullptr, 0, nullptr, 0, nullptr, 0, nullptr, max_pts);
+}
+
 extern "C++" {
 static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const double* G, const int64_t* tile_off,
                                        const int32_t* n_pts, int64_t n, const uint8_t* ray_mask,
                                        const int32_t* res, const int32_t* shape,
                                        double* H, int64_t* n_dropped, int32_t* work, hipStream_t stream,
                                        const double* const* Gs, int32_t n_freqs,
-                                       const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* H_minor) {
+                                       const int32_t* rest_list, int64_t n_rest, const int32_t* g_slot, int64_t g_room, double* H_minor,
+                                       int64_t max_pts) {
     if (!X || !Z || (!G && !Gs) || !tile_off || !n_pts || !res || !shape || !H) return fail("rt2d_heatmap_accumulate: null argument");
     if (n <= 0) return n == 0 ? 0 : fail("rt2d_heatmap_accumulate: negative ray count");
     if (res[0] <= 0 || res[1] <= 0) return fail("rt2d_heatmap_accumulate: resolution must be positive");
@@ -4051,6 +4062,11 @@ static int32_t heatmap_accumulate_impl(const double* X, const double* Z, const d
     static const int hm_cap = knob_pow2("RT2D_HM_CAP", 4096, 64, 8192);
     static const int hm_cells = knob_even("RT2D_HM_CELLS", 4096, 64, 16384);
     a.cap = hm_cap; a.cell_cap = hm_cells;
+    // Rays of tens of thousands of points (the reference's default step sizes: 100 001) have tens of thousands of candidate
+    // cells, and the general kernel walks the ray once per partition of its hash: twice the slots, half the walks (the side
+    // rays of the 65 536-ray default-step fan: 33 -> 16 ms).  Only when the caller says so (max_pts, or the room of a
+    // compact gain array): the LDS it costs takes a workgroup per CU away from ordinary rays.
+    if ((max_pts > 16384 || g_room > 16384) && !getenv("RT2D_HM_CAP")) a.cap = 8192;
     // the tile kernel walks a ray sequentially (latency ~ steps), the general kernel spreads one ray over a wave:
     // below ~6000 rays the latter finishes first (measured with the rows of a tile shared by up to 16 waves)
     static const int64_t fast_min_rays = getenv("RT2D_HEATMAP_FAST_MIN_RAYS") ? atoll(getenv("RT2D_HEATMAP_FAST_MIN_RAYS")) : 6000;

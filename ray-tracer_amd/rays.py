@@ -1074,10 +1074,16 @@ class RayFan:
             work = torch.empty(self.n + 2, dtype=torch.int32, device=self.device) if fast else None     # work list, no launch to mark it)
             if fast and hint:
                 ray_mask = self.heatmap_mask(res, shape, ray_mask)
-            _lib.check(L.rt2d_heatmap_accumulate(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
-                                                 self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
-                                                 _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),
-                                                 _raw_stream()))
+            # (what the host knows of the rays' lengths without asking the device: the general kernel sizes its hash by it)
+            max_pts = 0
+            if self._summary is not None:
+                max_pts = int(self._summary[1]) // TILE
+            elif self.tile_off is not None and not self._pending and self.total:
+                max_pts = int(self.total) // max(1, (self.n + TILE - 1) // TILE * TILE) * 4
+            _lib.check(L.rt2d_heatmap_accumulate_hinted(self.X.data_ptr(), self.Z.data_ptr(), self.G[freq].data_ptr(),
+                                                        self.tile_off.data_ptr(), self.n_pts.data_ptr(), self.n,
+                                                        _ptr(ray_mask), res_c, shape_c, H.data_ptr(), _ptr(dropped), _ptr(work),
+                                                        max_pts, _raw_stream()))
             self._last_slow = work if fast else self.n                   # rays binned by the general kernel: read on demand
 
 
