@@ -627,7 +627,7 @@ struct WaveLog {
 #define RT2D_TAB1_MAX_WAVES 4      // launch bound of the instances with all step tables in LDS (small fans, one wave per workgroup):
                                    // 256 vector registers instead of 128, so that the straight-line rebound does not spill
 template <bool WRITE, int TAB, int POST, bool CUTOFF, bool CEILC, int FUSE = 0>
-__global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE : FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : TAB == 1 ? RT2D_TAB1_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
+__global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE : FUSE ? RT2D_FUSE_MAX_WAVES * RT2D_WAVE : (TAB == 1 || TAB == 3) ? RT2D_TAB1_MAX_WAVES * RT2D_WAVE : 1024) rt2d_cast_kernel(const CastArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_mem[];
     constexpr int COLD_DOUBLES = (sizeof(CastCold) + 7) / 8;
     CastCold* cold = reinterpret_cast<CastCold*>(s_mem);
@@ -636,6 +636,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         cold->dx_floor = a.env.dx_floor; cold->dx_ceil = a.env.dx_ceil; cold->out = a.out; cold->n = a.n;
         cold->rebound_cap = a.p.rebound_cap; cold->n_rebounds_max = a.p.n_rebounds_max;
     }
+    // TAB = 3: the tables of 2 (sound speed in LDS, the rest through the caches) with the launch bound and the rebound forms of 1:
+    // a small fan that must leave the LDS to a kernel running beside it (RT2D_LAUNCH_SMALL_LDS).
     // TAB: where the step tables are read from.  1: the whole step section staged in LDS (small fans: one wave per CU, the
     // LDS round trip is on the critical path of every step).  2: only the sound-speed table (the blob's first table, a few
     // KB) in LDS, floor and surface through L1 / L2 (large fans: workgroups of a few waves, many per CU, so that the
@@ -643,11 +645,11 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // of 16 waves, whose slots stay empty from the first wave that ends to the last).  0: everything through L1 / L2.
     const double* tab_cz;       // sound speed
     const double* tab_fl;       // floor and surface
-    const int n_stage = FUSE ? a.fuse_step_doubles : (TAB == 2 ? a.env.cz_doubles : a.env.step_doubles);
+    const int n_stage = FUSE ? a.fuse_step_doubles : ((TAB == 2 || TAB == 3) ? a.env.cz_doubles : a.env.step_doubles);
     if (TAB != 0) {
         for (int i = threadIdx.x; i < n_stage; i += blockDim.x) s_tab[i] = a.blob[i];
         tab_cz = s_tab;
-        if (TAB == 2 && !FUSE) tab_fl = a.blob; else tab_fl = s_tab;
+        if ((TAB == 2 || TAB == 3) && !FUSE) tab_fl = a.blob; else tab_fl = s_tab;
     } else {
         tab_cz = a.blob; tab_fl = a.blob;
     }
@@ -656,7 +658,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         const double* src_abs = a.blob + a.env.gain_off + a.env.absorb.off;
         for (int i = threadIdx.x; i < a.fuse_abs_doubles; i += blockDim.x) s_abs[i] = src_abs[i];
     }
-    const double* tab_slope = (FUSE || TAB == 2) ? a.blob : tab_fl;         // where the slope tables are read from
+    const double* tab_slope = (FUSE || TAB == 2 || TAB == 3) ? a.blob : tab_fl;         // where the slope tables are read from
     __syncthreads();
     WaveLog wave_log(a);
     // Ray of this lane.  A wave executes the rebound branch whenever ANY of its lanes rebounds, which with 64 rays is
@@ -813,7 +815,8 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // points, the choice of the division) is carried through it.  The step that the wave cannot take together is left
     // untouched for the general loop, which then tries the tight loop again.  (The waves of a small fan hold four shallow
     // rays that rebound twenty times in 1500 steps: they spend nine steps in ten here.)
-    constexpr bool TIGHT = !CUTOFF && (FUSE == 0) && (POST <= 1 || TAB == 1);     // (with the whole post-pass only where 256
+    constexpr bool SMALLF = (TAB == 1 || TAB == 3);      // the instances of few waves per CU: 256 registers, rebounds in straight-line form
+    constexpr bool TIGHT = !CUTOFF && (FUSE == 0) && (POST <= 1 || SMALLF);     // (with the whole post-pass only where 256
                                                                                     // registers are to be had: it needs 175)
     bool tight_on = TIGHT && !(WRITE && a.C != nullptr) && !want_margin && a.tight_off != 1 && !(FULL && a.tight_off == 2);      // (the decision margin is a test output: general loop)
     // Wave-uniform facts the tight loop leans on, established once:
@@ -1005,7 +1008,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 // instances): the exit into the general loop and back costs more than the rebound itself.  The expressions are
                 // those of the general step for such a wave (the IEEE k1/k0 for every ray, as there when one ray rebounds).
                 auto mixed_step = [&]() -> bool {
-                    if (TAB != 1 || !(i < tight_end) || (ST && steep_t == 0ull)) return false;
+                    if (!SMALLF || !(i < tight_end) || (ST && steep_t == 0ull)) return false;
                     const bool in_x = (xn >= ta[0]) & (xn < ta[3]) & (CEILC | ((xn >= tb[0]) & (xn < tb[3])));
                     const bool form = ST | (!(fabs(dx_z) > dx_z_max) & (fabs(kz_s) >= 1e-250));
                     const double z_ce = CEILC ? a.ceil_const : zc_t;
@@ -1153,7 +1156,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         // The ordinary rebound in its straight-line form (rebound_examine above); a lane that fails any test is left,
         // untouched, to the general case.
         bool reb_done = false;
-        if (TIGHT && TAB == 1 && !want_margin && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
+        if (TIGHT && SMALLF && !want_margin && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
             const bool hitf = z_new < z_floor;
             const bool hitc = !hitf & (z_new > z_ceil);
             const bool cand = general & oka & okb & (x_new >= e.range_min[0]) & (x_new <= e.range_max[0]) & (hitf | (CEILC & hitc));
@@ -3421,7 +3424,13 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     const int64_t rays_per_block = (int64_t)(block / RT2D_WAVE) * a.lanes;
     const int64_t grid = (n + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
-    if (hybrid) {
+    if (hybrid && small_lds && WRITE && POST == 1 && !CUTOFF && env->ceil_is_const && block <= RT2D_TAB1_MAX_WAVES * RT2D_WAVE) {
+        // (the one combination the side rays of rt2d_cast_heatmap are cast with; every other one takes the instance below)
+        auto k = rt2d_cast_kernel<WRITE, 3, (POST == 1 ? 1 : 0), false, true>;
+        a.ceil_const = env->ceil_const;
+        ALLOW_LDS(k, lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
+    } else if (hybrid) {
         auto k = env->ceil_is_const ? rt2d_cast_kernel<WRITE, 2, POST, CUTOFF, true> : rt2d_cast_kernel<WRITE, 2, POST, CUTOFF, false>;
         a.ceil_const = env->ceil_const;
         ALLOW_LDS(k, lds);
