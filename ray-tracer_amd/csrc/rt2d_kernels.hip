@@ -1618,8 +1618,8 @@ __global__ void __launch_bounds__(256) rt2d_reb_scatter_kernel(const GainArgs a,
     a.G[(int64_t)blockIdx.y * a.total + o] += loss[((int64_t)blockIdx.y * a.rebound_cap + k) * a.n + r];
 }
 
-template <int FCH, bool LOSS>
-__global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
+template <int FCH, bool LOSS, bool FULL>       // FULL: G is written and every group of the launch has FCH frequencies
+__global__ void __launch_bounds__(256, (FCH == 8 && FULL) ? 3 : 1) rt2d_gain_kernel(const GainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     for (int i = threadIdx.x; i < a.env.gain_doubles; i += blockDim.x) s_tab[i] = a.blob[a.env.gain_off + i];
     __syncthreads();
@@ -1627,7 +1627,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n) return;
     const int f0 = blockIdx.y * FCH;
-    const int nf = min(FCH, a.n_freqs - f0);
+    const int nf = FULL ? FCH : min(FCH, a.n_freqs - f0);
     const DevTable& ab = a.env.absorb;
     const int np = rt2d_stored_pts(a.n_pts, a.tile_off, r);
     const int64_t base = a.tile_off[r >> 6] + (r & 63);
@@ -1645,29 +1645,32 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
     int next_reb_at = (nreb > 0) ? a.reb_step[r] + 1 : 0x7fffffff;         // first point index that carries the loss
 
     double xp = a.X[base], zp = a.Z[base];
-    if (a.G) {
+    if (FULL || a.G) {
 #pragma unroll
         for (int k = 0; k < FCH; ++k) if (k < nf) a.G[(int64_t)(f0 + k) * a.total + base] = 0.0;
     }
     // the next GAIN_AHEAD points of the ray are in flight while one is worked on (a slot is refilled as soon as it is read).
     // Measured on 1M rays: 1 ahead 6.9 ms, 4 ahead 8.4 ms -- the kernel is bound by its ~130 instructions per step, not by
     // HBM latency, and the extra registers cost occupancy.
+    // The next point is loaded one iteration ahead, at the TOP of the iteration (the empty asm keeps the loads above the
+    // stores): on this architecture stores count in the same counter as loads and complete in order, so a load issued
+    // behind the n_st stores of an iteration is only back when those have reached memory.  Nothing is outstanding when the
+    // loop is entered, so that the wait the compiler places at the first use is counted from the loop's own operations.
+    auto load_point = [&](int row, double& xo, double& zo) {
+        const int64_t on = base + (int64_t)min(row, max(np, 1) - 1) * RT2D_WAVE;      // (clamped into the ray: unconditional)
+        xo = a.X[on]; zo = a.Z[on];
+    };
+    double xq, zq;
+    load_point(1, xq, zq);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
     constexpr int GAIN_AHEAD = 1;
-    double xq[GAIN_AHEAD], zq[GAIN_AHEAD];
-#pragma unroll
-    for (int u = 0; u < GAIN_AHEAD; ++u) {
-        const bool live = 1 + u < np;
-        xq[u] = live ? a.X[base + (int64_t)(1 + u) * RT2D_WAVE] : 0.0;
-        zq[u] = live ? a.Z[base + (int64_t)(1 + u) * RT2D_WAVE] : 0.0;
-    }
     for (int s0 = 1; s0 < np; s0 += GAIN_AHEAD) {
-#pragma unroll
-      for (int u = 0; u < GAIN_AHEAD; ++u) {
-        const int s = s0 + u;
-        if (s >= np) break;
+      {
+        const int s = s0;
         int64_t o = base + (int64_t)s * RT2D_WAVE;
-        double x = xq[u], z = zq[u];
-        if (s + GAIN_AHEAD < np) { xq[u] = a.X[o + GAIN_AHEAD * RT2D_WAVE]; zq[u] = a.Z[o + GAIN_AHEAD * RT2D_WAVE]; }
+        double x = xq, z = zq;
+        load_point(s + 1, xq, zq);
+        asm volatile("" ::: "memory");
         double ddx = x - xp, ddz = z - zp;
         double dL = sqrt(ddx * ddx + ddz * ddz);
         // six depth factors at the START point of the segment (ray.py:346 uses XZ[:-1, 1])
@@ -1708,7 +1711,7 @@ __global__ void __launch_bounds__(256) rt2d_gain_kernel(const GainArgs a) {
             double alpha = alpha_1 * E1 + alpha_2 * E2 + alpha_3 * E3;
             double dG = rt2d_div_1000(-1 * alpha) * dL;                            // ray.py:346
             S[k] += dG;                                                    // ray.py:347
-            if (a.G && k < nf) a.G[(int64_t)(f0 + k) * a.total + o] = S[k] + A[k];
+            if (FULL || (a.G && k < nf)) a.G[(int64_t)(f0 + k) * a.total + o] = S[k] + A[k];
         }
         xp = x; zp = z;
       }
@@ -3784,17 +3787,22 @@ int32_t rt2d_gain(rt2d_env_t env, const double* X, const double* Z, const int64_
     const int block = (n <= 64 * 512) ? 64 : 256;
     dim3 grid((unsigned)((n + block - 1) / block), (unsigned)((n_freqs + fch - 1) / fch));
     void (*kern)(const GainArgs);
+    // every group full and G written: the stores of an iteration are a fixed count, which lets the wait for the next point
+    // be a counted one (see the kernel)
+    const bool full = a.G && n_freqs % fch == 0 && !getenv("RT2D_GAIN_NOT_FULL");
     if (loss_ws && rebound_cap > 0) {
         // rebound losses first, one thread per (ray, rebound, frequency); the gain loop then only reads them
         const int64_t pairs = n * rebound_cap;
         hipLaunchKernelGGL(rt2d_reb_loss_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)n_freqs), dim3(256), 0,
                            (hipStream_t)stream, a, loss_ws, 0.0);
         a.loss = loss_ws;
-        kern = fch == 8 ? rt2d_gain_kernel<8, true> : fch == 4 ? rt2d_gain_kernel<4, true>
-             : fch == 2 ? rt2d_gain_kernel<2, true> : rt2d_gain_kernel<1, true>;
+        kern = full ? (fch == 8 ? rt2d_gain_kernel<8, true, true> : fch == 4 ? rt2d_gain_kernel<4, true, true>
+                     : fch == 2 ? rt2d_gain_kernel<2, true, true> : rt2d_gain_kernel<1, true, true>)
+                    : (fch == 8 ? rt2d_gain_kernel<8, true, false> : fch == 4 ? rt2d_gain_kernel<4, true, false>
+                     : fch == 2 ? rt2d_gain_kernel<2, true, false> : rt2d_gain_kernel<1, true, false>);
     } else {
-        kern = fch == 8 ? rt2d_gain_kernel<8, false> : fch == 4 ? rt2d_gain_kernel<4, false>
-             : fch == 2 ? rt2d_gain_kernel<2, false> : rt2d_gain_kernel<1, false>;
+        kern = fch == 8 ? rt2d_gain_kernel<8, false, false> : fch == 4 ? rt2d_gain_kernel<4, false, false>
+             : fch == 2 ? rt2d_gain_kernel<2, false, false> : rt2d_gain_kernel<1, false, false>;
     }
     ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, dim3(block), lds, (hipStream_t)stream, a);
