@@ -2474,12 +2474,16 @@ __global__ void __launch_bounds__(256) rt2d_heatmap_fast_kernel(const HeatArgs a
     // the runs of equal cells across the wave are the same for every frequency: they are worked out once per point and
     // only the value (2^x of that frequency's gain) and the run sums are per frequency.
     const int f0 = (FB > 1) ? (int)blockIdx.y * FB : 0;
-    const double* Gk[FB];
+    // (the per-map gain pointers are read from device memory, and a pointer that was loaded is a generic one to the
+    // compiler: the gains would be FLAT loads, which count in the vector-memory AND the LDS counter and turn every wait of
+    // the walk -- the LDS queue's included -- into a wait for both to drain.  They are global memory: said here.)
+    typedef const __attribute__((address_space(1))) double* g_cf64p;
+    g_cf64p Gk[FB];
     double* Hk[FB];
 #pragma unroll
     for (int k = 0; k < FB; ++k) {
         const int f = (FB > 1) ? min(f0 + k, a.n_freqs - 1) : 0;      // a group past the end repeats the last map's gains ...
-        Gk[k] = (FB > 1) ? a.Gs[f] : a.G;
+        Gk[k] = (g_cf64p)((FB > 1) ? a.Gs[f] : a.G);
         Hk[k] = a.H + (int64_t)f * a.map_stride;
     }
     const int nf = (FB > 1) ? min(FB, a.n_freqs - f0) : 1;            // ... but only deposits the first nf
@@ -2903,7 +2907,7 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                         if (own[u] >= 0) own_q[__popcll(om & ((1ull << wl) - 1ull))] = make_int2(own[u], own_s[u]);
                         for (int g = 0; g < n_groups; ++g) {
                             const int f = g * FBG + kq;
-                            const double* Gf = a.Gs[min(f, a.n_freqs - 1)];
+                            const auto Gf = (const __attribute__((address_space(1))) double*)a.Gs[min(f, a.n_freqs - 1)];   // (global, not FLAT)
                             double* Hg = a.H_minor + (int64_t)g * a.map_stride * FBG;
                             for (int e0 = 0; e0 < c; e0 += SPW) {
                                 const int e = e0 + dq;
@@ -2917,7 +2921,7 @@ __global__ void __launch_bounds__(HM_THREADS) rt2d_heatmap_kernel(const HeatArgs
                 } else {
                     // several maps: the owning step of a cell is the same for every frequency, only the value differs
                     for (int f = 0; f < a.n_freqs; ++f) {
-                        const double* Gf = a.Gs[f];
+                        const auto Gf = (const __attribute__((address_space(1))) double*)a.Gs[f];
                         double* Hf = a.H + (int64_t)f * a.map_stride;
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
