@@ -247,11 +247,14 @@ def test_heatmap_backward_and_out_of_map_rays(rt, orc):
     assert np.abs(Hd.cpu().numpy() - Hs).max() <= 1e-12 * Hs.max()
 
 
-def test_gain_two_phase_equals_one_pass(rt, monkeypatch):
+@pytest.mark.parametrize('n_freqs', [3, 16, 4, 2, 1])
+def test_gain_two_phase_equals_one_pass(rt, monkeypatch, n_freqs):
     """Small fans take the two-phase gain (per-point dG, then running sums), large ones the one-pass kernel: same
-    expressions in the same order, so the arrays must be identical bit for bit."""
+    expressions in the same order, so the arrays must be identical bit for bit.  3 frequencies: a group of four that is not
+    full; 16 / 4 / 2 / 1: the instances of the one-pass kernel whose groups are all full (stores without a condition, the
+    wait for the next point counted by the compiler)."""
     g = common.load('c2_fan999')
-    freqs = [1., 1000., 20000.]
+    freqs = [1., 1000., 20000.] if n_freqs == 3 else [float(f) for f in np.geomspace(1., 20000., n_freqs)]
     fan, env = _cast(rt, g)
     fan.populate(*freqs)
     monkeypatch.setenv('RT2D_GAIN_TWO_PHASE_MAX_RAYS', '0')
