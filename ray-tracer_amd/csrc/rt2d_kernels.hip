@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
     // untouched for the general loop, which then tries the tight loop again.  (The waves of a small fan hold four shallow
     // rays that rebound twenty times in 1500 steps: they spend nine steps in ten here.)
     constexpr bool SMALLF = (TAB == 1 || TAB == 3);      // the instances of few waves per CU: 256 registers, rebounds in straight-line form
-    constexpr bool TIGHT = !CUTOFF && (FUSE == 0) && (POST <= 1 || SMALLF);     // (with the whole post-pass only where 256
+    constexpr bool TIGHT = !CUTOFF && (FUSE == 0 || SMALLF) && (POST <= 1 || SMALLF);     // (with the whole post-pass only where 256
                                                                                     // registers are to be had: it needs 175)
     bool tight_on = TIGHT && !(WRITE && a.C != nullptr) && !want_margin && a.tight_off != 1 && !(FULL && a.tight_off == 2);      // (the decision margin is a test output: general loop)
     // Wave-uniform facts the tight loop leans on, established once:
@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                 // instances): the exit into the general loop and back costs more than the rebound itself.  The expressions are
                 // those of the general step for such a wave (the IEEE k1/k0 for every ray, as there when one ray rebounds).
                 auto mixed_step = [&]() -> bool {
-                    if (!SMALLF || !(i < tight_end) || (ST && steep_t == 0ull)) return false;
+                    if (!SMALLF || FUSE || !(i < tight_end) || (ST && steep_t == 0ull)) return false;      // (FUSE: a rebound's loss is the general step's business)
                     const bool in_x = (xn >= ta[0]) & (xn < ta[3]) & (CEILC | ((xn >= tb[0]) & (xn < tb[3])));
                     const bool form = ST | (!(fabs(dx_z) > dx_z_max) & (fabs(kz_s) >= 1e-250));
                     const double z_ce = CEILC ? a.ceil_const : zc_t;
@@ -1069,6 +1069,17 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                             const double dL = rt2d_sqrt_fast(ddx * ddx + ddz * ddz);
                             L += dL; T += rt2d_div_fast(dL, c_pt);
                         }
+                        double g_pt_t = 0.0;
+                        if (FUSE) {                                                       // the general step's gain (ray.py:346-347)
+                            const double ddx = xn - x, ddz = zn - z;
+                            const double dL = rt2d_sqrt_fast(ddx * ddx + ddz * ddz);
+                            double rec[20];
+                            rt2d_lookup<19>((const double*)s_abs, ab_lds, z, rec);
+                            const double dG = rt2d_div_1000(-1 * rt2d_alpha(rec, z - rec[0], g_ff)) * dL;
+                            g_S += dG;
+                            g_pt_t = g_S + g_A;
+                            g_A += g_pend; g_pend = 0.0;
+                        }
                         x = xn; z = zn;
                         const double dzr_t = z - tz8[0];
                         c = rt2d_quad_of(tz8, dzr_t, 0);
@@ -1079,6 +1090,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
                         }
                         if (POST >= 1) { min_z = vmin(min_z, z); max_z = vmax(max_z, z); }
                         if (WRITE) { p_off += P_STEP; put(tx_base, p_off, x); put(tz_base, p_off, z); }
+                        if (FUSE) binner.point(a.bin, x, z, g_pt_t, lane);
                         if (ST) {
                             dx_z = rt2d_div_fast(kz_s, kx_s);                                 // k1/k0 (ray.py:243)
                         } else {
@@ -1156,7 +1168,7 @@ __global__ void __launch_bounds__(FUSE == 2 ? RT2D_FUSE2_MAX_WAVES * RT2D_WAVE :
         // The ordinary rebound in its straight-line form (rebound_examine above); a lane that fails any test is left,
         // untouched, to the general case.
         bool reb_done = false;
-        if (TIGHT && SMALLF && !want_margin && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
+        if (TIGHT && SMALLF && !FUSE && !want_margin && __builtin_expect(rt2d_any(general), 0)) {     // (small fans: their waves wait on every rebound)
             const bool hitf = z_new < z_floor;
             const bool hitc = !hitf & (z_new > z_ceil);
             const bool cand = general & oka & okb & (x_new >= e.range_min[0]) & (x_new <= e.range_max[0]) & (hitf | (CEILC & hitc));
@@ -3374,7 +3386,10 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
     // kilometres apart (count pass of 65 536 rays at the default step sizes 108 -> 78 ms with everything in LDS, 131 072
     // rays 112 -> 82 ms; at dx_max 50 / dz_max 25: 32 768 rays stored 1.94 -> 1.42 ms, 65 536 1.88 -> 1.44, 131 072
     // 1.74 -> 1.51, 262 144 2.15 -> 2.28).  RT2D_LAUNCH_SMALL_LDS asks for it whatever the size.
-    const bool small_lds = a.p.launch_hint == RT2D_LAUNCH_SMALL_LDS;
+    // ... and so does a small fan whose step tables do not fit in LDS at all (the 100 km floor of tests_3.ipynb: 166 KB):
+    // the sound speed from LDS and the small-fan forms of the loop instead of every record through the caches
+    const bool small_lds = a.p.launch_hint == RT2D_LAUNCH_SMALL_LDS
+                        || (!in_lds && tab_env < 0 && n <= n_cu * RT2D_WAVE && !getenv("RT2D_NO_SMALL_HYBRID"));
     const bool hybrid = (n > n_cu * RT2D_WAVE * 8 || small_lds) && cold + cz_bytes <= 32 * 1024 && tab_env != 0 && tab_env != 1;
     const size_t lds = cold + (hybrid ? cz_bytes : in_lds ? tab_bytes : 0);
     // Launch shape.  Measured on MI355X (tools/microbench_lanes.py): a wave steps fastest when it is alone on its CU
@@ -3429,6 +3444,7 @@ static int32_t launch_cast2(rt2d_env_t env, const CastArgs& a_in, hipStream_t st
         block = wpb * RT2D_WAVE;
     }
     const int64_t rays_per_block = (int64_t)(block / RT2D_WAVE) * a.lanes;
+    if (getenv("RT2D_DEBUG_LDS")) fprintf(stderr, "[rt2d] cast: n %lld cold %zu tab %zu cz %zu hybrid %d in_lds %d lds %zu block %d lanes %d\n", (long long)n, cold, tab_bytes, cz_bytes, (int)hybrid, (int)in_lds, lds, block, a.lanes);
     const int64_t grid = (n + rays_per_block - 1) / rays_per_block;
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     if (hybrid && small_lds && WRITE && POST == 1 && !CUTOFF && env->ceil_is_const && block <= RT2D_TAB1_MAX_WAVES * RT2D_WAVE) {
@@ -3604,6 +3620,8 @@ int32_t rt2d_cast_heatmap(rt2d_env_t env, const double* angles, int64_t n, const
     const int block = waves * RT2D_WAVE;
     const size_t lds = cold + tab_bytes + (size_t)waves * per_wave;
     const int64_t grid = (n + block - 1) / block;
+    if (getenv("RT2D_DEBUG_LDS")) fprintf(stderr, "[rt2d] fused: cold %zu tab %zu waves %d lds %zu grid %lld; pieces: cz %d floor %d surface %d floor slope %d surface slope %d absorption %d\n", cold, tab_bytes, waves, lds, (long long)grid,
+                                          env->dev.cz.n_pieces, env->dev.floor.n_pieces, env->dev.ceil.n_pieces, env->dev.dx_floor.n_pieces, env->dev.dx_ceil.n_pieces, env->dev.absorb.n_pieces);
     if (grid > 0x7fffffff) return fail("too many rays for one launch");
     a.fuse_loss = loss; a.fuse_loss_cap = loss ? loss_cap : 0;
     auto k = loss ? (env->ceil_is_const ? rt2d_cast_kernel<false, 1, 1, false, true, 2> : rt2d_cast_kernel<false, 1, 1, false, false, 2>)
