@@ -683,6 +683,8 @@ class RayFan:
         with torch.cuda.device(self.device):
             sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
             mask = self.fused_mask(res, shape, ray_mask)
+            if self.__dict__.get('_exact_binning'):          # an earlier pass met a ray its binner could not take: every ray the stored way
+                mask = torch.zeros_like(mask)
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
             src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
@@ -709,7 +711,7 @@ class RayFan:
                 # (power_cutoff): every ray goes through the stored path, a chunk at a time
                 self.fused_unavailable = L.rt2d_last_error().decode()
                 rest = torch.nonzero(sel).flatten()
-            self.last_fused_violations = viol
+            self.last_fused_violations = self._viol_pending = viol
             self._bin_side_rays(rest, H, res, shape, freq, dropped, fast=rc != 0, after=before)
 
     def _bin_side_rays(self, rest, H, res, shape, freq, dropped, fast=False, after=None):
@@ -792,7 +794,7 @@ class RayFan:
                 self._uncast = False
                 if not adopt:
                     self._cast(self._init_host, False, alloc_only=True)
-            checks, slow, slows = [], 0, []
+            checks, slow, slows, viols = [], 0, [], []
             # chunks alternate between two streams, each starting when the previous chunk's CAST is done: the long last
             # waves of one chunk's kernels (a chunk is one round of waves: its kernels last as long as its longest ray)
             # run beside the next chunk's
@@ -829,6 +831,8 @@ class RayFan:
                 else:
                     sub = self.subset(np.arange(c0, c1))
                     sub._need_store()
+                if self.__dict__.get('_exact_binning'):
+                    sub._exact_binning = True
                 cast_done = lane_stream.record_event()
                 mask = (sub.status == 0) if ray_mask is None else ((sub.status == 0) & (ray_mask[c0:c1] != 0))
                 # (a chunk's summary -- did it fit its provisional layout, did a one-pass map have rows enough for its side
@@ -836,6 +840,8 @@ class RayFan:
                 sub.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask.to(torch.uint8), dropped=dropped,
                                        defer=first and sub._pending)
                 sub._pending = False
+                if sub.__dict__.get('_viol_pending') is not None:
+                    viols.append(sub._viol_pending)
                 w = getattr(sub, '_last_slow', 0)           # an int, or the work list of rt2d_heatmap_accumulate ([0] < 0: every ray)
                 slows.append(w if isinstance(w, int) else torch.where(w[0] < 0, torch.full_like(w[0], sub.n), w[0]))
                 del sub
@@ -844,6 +850,10 @@ class RayFan:
             for w in slows:
                 slow = slow + w
             self.last_fused_violations = torch.zeros(1, dtype=torch.int64, device=self.device)
+            for v in viols:
+                self.last_fused_violations = self.last_fused_violations + v
+            if viols:
+                self._viol_pending = self.last_fused_violations
             self._last_slow = slow if isinstance(slow, int) else slow.reshape(1)
             if first:
                 if not adopt:
@@ -899,7 +909,7 @@ class RayFan:
                                                     _ptr(dropped), viol.data_ptr(), _ptr(loss_ws),
                                                     torch.empty(rows + 2, dtype=torch.int32, device=self.device).data_ptr(), stream))
                 self._last_slow = rest_list            # ([0] = the number of side rays: read on demand)
-                self.last_fused_violations = viol
+                self.last_fused_violations = self._viol_pending = viol
                 return
             self.validate()                              # the masks below need the final cast
             self._onepass_overflow = False
@@ -928,7 +938,7 @@ class RayFan:
                                                 _ptr(dropped), viol.data_ptr(), _ptr(loss_ws),
                                                 torch.empty(n_rest + 2, dtype=torch.int32, device=self.device).data_ptr(), stream))
             self.last_slow_rays = n_rest
-            self.last_fused_violations = viol
+            self.last_fused_violations = self._viol_pending = viol
 
     def heatmap_accumulate_multi(self, H, res, shape, freqs, ray_mask=None, dropped=None):
         """Adds this fan's rays into the maps of several frequencies at once (H: (F, nx*nz) device f64, contiguous): one
@@ -1061,6 +1071,8 @@ class RayFan:
             return self.heatmap_accumulate_fused(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped)
         if stream is None:
             stream = fast and freq not in self.G and self.n >= STREAM_MIN_RAYS
+        if self.__dict__.get('_exact_binning'):
+            stream = False                       # (a one-pass binning of this fan met a ray it could not take: gain array + binning kernels)
         if stream:
             return self.heatmap_accumulate_stream(H, res, shape, freq=freq, ray_mask=ray_mask, dropped=dropped, defer=defer)
         torch = _torch()

@@ -199,6 +199,8 @@ class Simulation2D:
                         ext[4] = ((sd[1] > float(fan._room * 64)) | (sd[2] != 0) | (sd[8] != 0)).to(torch.float64)
                     if distinct is not None:
                         ext[4] = torch.maximum(ext[4], (~distinct).to(torch.float64))
+                    if fan.__dict__.get('_viol_pending') is not None:         # (a ray the one pass could not bin: all ranks start over)
+                        ext[4] = torch.maximum(ext[4], (fan._viol_pending[0] != 0).to(torch.float64))
                 else:
                     ext[4] = 1.0
                 parallel._all_reduce(ext, parallel._dist().ReduceOp.MAX)
@@ -216,6 +218,7 @@ class Simulation2D:
             if dist_on:
                 got = ext.tolist()
                 fan.validate()                                # (a fan that must be cast again is, before every rank starts over)
+                self._violated([fan])                         # (marks this rank's fan; the verdict itself travelled in got[4])
                 if got[4] != 0:
                     return None
                 rmin, rmax = -np.array(got[0:2]), np.array(got[2:4])
@@ -224,8 +227,11 @@ class Simulation2D:
                 shape = parallel.heatmap_shape(rmin, rmax, res)
                 return H.view(int(shape_b[0]), int(shape_b[1])), out_b, shape, dropped
             if fan.validate() or getattr(fan, '_onepass_overflow', False):
+                fan.__dict__.pop('_viol_pending', None)
                 return None                                   # cast again with counted sizes, or a one-pass map without rows
                                                               # enough for its side rays: start over
+            if self._violated([fan]):
+                return None                                   # a ray the one pass could not bin exactly: start over, the exact way
             if distinct is not None and not bool(distinct.item()):
                 return None                                   # repeated angles: the pack keeps the first of each
         summ = fan._summary
@@ -234,6 +240,25 @@ class Simulation2D:
             return None
         shape = parallel.heatmap_shape(rmin, rmax, res)
         return H.view(int(shape_b[0]), int(shape_b[1])), out_b, shape, dropped
+
+    def _violated(self, fans, dist_on=False, device=None):
+        """True when a one-pass or fused binning queued by this call met a ray that its binner could not bin exactly (the
+        masks are meant to keep such rays out: RayFan.fused_mask, rt2d_classify_rays; the kernels count what slips through,
+        RayFan.last_fused_violations).  The map is then incomplete: the fans are marked so that their rays take the gain
+        array + binning kernels from now on, and the caller starts over.  Among ranks the verdict is shared (a maximum), so
+        that all of them start over together."""
+        torch = _torch()
+        flag = 0
+        for fan in fans:
+            v = fan.__dict__.pop('_viol_pending', None)
+            if v is not None and int(v.item()) != 0:
+                fan._exact_binning = True
+                flag = 1
+        if dist_on:
+            t = torch.tensor([float(flag)], dtype=torch.float64, device=device)
+            parallel._all_reduce(t, parallel._dist().ReduceOp.MAX)
+            flag = int(t.item())
+        return bool(flag)
 
     def heatmap_full(self, **kwargs):
         """Un-normalised heat map (nx, nz) as a device tensor, plus the number of dropped points."""
@@ -273,6 +298,8 @@ class Simulation2D:
                 continue
             fan.heatmap_accumulate(H, res, shape, freq=freq, ray_mask=mask, dropped=dropped, fast=kwargs.get('fast', True),
                                    hint=kwargs.get('hint', True), stream=kwargs.get('stream', None))
+        if self._violated([fan for fan, _ in segs], dist_on, device):
+            return self._heatmap(kwargs, finalize)                       # (the fans now take the exact binning: once more)
         if dist_on:                                                       # C2: sum of the ranks' maps
             parallel.allreduce_heatmap(H)
             parallel._all_reduce(dropped, parallel._dist().ReduceOp.SUM)

@@ -91,6 +91,36 @@ def test_fused_kernel_flags_a_ray_it_cannot_bin(rt):
     assert bool((irr[(fan.monotone == 0) & (fan.status == 0)] == 1).all().item())
 
 
+def test_a_ray_that_slips_through_the_mask_makes_the_map_start_over(rt, monkeypatch):
+    """The masks are meant to keep every ray the one-pass binner cannot take out of it.  Should one slip through -- here the
+    mask is made to vouch for rays that turn back -- the kernels count it (last_fused_violations) and the map would be
+    incomplete: heatmap() must notice, mark the fan and bin it again the exact way.  Both forms: the fused kernel of a
+    store=False fan and the one pass over stored trajectories."""
+    import torch
+    from ray_tracer_amd import rays as rays_mod
+    g = common.load('c2_fan999')
+    env = common.product_env(rt, g)
+    kw = common.prop_kwargs(g)
+    ref_sim = rt.Simulation2D(env, g['fan_source'])
+    ref_sim.cast(g['fan_angles'], **kw)
+    Hs = ref_sim.heatmap_full(resolution=[50, 25], stream=False)[0].cpu().numpy()
+
+    def vouch_for_all(self, res, shape, ray_mask=None):
+        ok = self.status == 0
+        if ray_mask is not None:
+            ok = ok & (ray_mask != 0)
+        return ok.to(torch.uint8)
+    monkeypatch.setattr(rays_mod.RayFan, 'fused_mask', vouch_for_all)
+    for store, extra in ((False, {}), (True, {'stream': True})):
+        sim = rt.Simulation2D(env, g['fan_source'])
+        fan = sim.cast(g['fan_angles'], store=store, **kw)
+        assert int(((fan.monotone == 0) & (fan.status == 0)).sum().item()) > 0
+        H = sim.heatmap_full(resolution=[50, 25], **extra)[0].cpu().numpy()
+        assert fan.__dict__.get('_exact_binning') is True
+        assert np.array_equal(H == 0, Hs == 0)
+        assert (np.abs(H - Hs)[Hs != 0] / Hs[Hs != 0]).max() < 1e-12
+
+
 def test_fused_at_default_resolution(rt):
     """dx_max = 10, dz_max = 0.1 (preferences.py:6-7): up to 100 001 points per ray, the case the fused kernel exists for
     (a stored 1 M-ray fan would need 1.6 TB).  64 rays on the c2 environment, fused against stored."""

@@ -65,7 +65,7 @@ def test_random_environment_bit_exact(rt, orc, seed):
           f'{int((fan.host("status") != 0).sum())} ray errors, kw {kw}')
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', range(9))      # (seed 8: the clipped last point of a ray jumps eight rows inside its column)
 def test_random_environment_heat_maps_agree(rt, seed):
     """The three ways to a heat map -- stored trajectories + gain + binning kernels, one pass over stored trajectories,
     fused cast+gain+binning -- on random environments, cell sizes and frequencies: same map to 1e-12."""
