@@ -203,8 +203,11 @@ int32_t rt2d_cast_write(rt2d_env_t env, const double* angles, int64_t n, const d
  * rt2d_heatmap_accumulate into the same H.
  * sign multiplies every deposited value (1.0 normally).  out: only n_pts, stop_code, n_rebounds, status, range,
  * monotone, slope_max (may be NULL).  irregular (device, n bytes, may be NULL) / n_violations (device int64, may be
- * NULL, caller zeroes it): a ray that breaks the precondition stops being binned, is flagged and counted -- with a
- * ray_mask built as above the count is 0; otherwise H is not the reference's map.
+ * NULL, caller zeroes it): a ray that breaks the precondition stops being binned, is flagged and counted.  A count
+ * other than 0 means H is NOT the reference's map and the caller must bin again with the flagged rays left to the stored
+ * path: ALWAYS read it.  The slope bound above is exact for plain steps only -- a rebound ends on the surface under the
+ * hit abscissa (ray.py:177-178), which on a rough floor can lie far off the line of the step -- so a mask built as above
+ * makes the count 0 on every fixture, not on every environment (the host side starts over: Simulation2D._violated).
  * loss / loss_cap: optional (NULL, 0): the rebound losses at `freq` of these same rays from rt2d_rebound_loss over the
  * rebound log of the prior cast, entry k of ray r at [k*n + r], k < loss_cap.  The propagation is deterministic, so the
  * k-th rebound met here is the k-th logged one; the kernel then carries no reflection-coefficient code (sincos, hypot,
