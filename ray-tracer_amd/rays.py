@@ -407,7 +407,8 @@ class RayFan:
     def validate(self):
         """The one device -> host read of a single-pass cast (64 bytes): [points of the exact layout, longest tile, a
         rebound log overflowed, rays without error, plot range x 4].  If a ray outgrew the room of the provisional layout
-        or a rebound log overflowed, the fan is cast again with counted sizes (and anything derived from it is dropped).
+        or a rebound log overflowed, the fan is cast again with counted sizes (what was derived from it is dropped; gains that
+        had been populated are populated again).
         Returns True when the fan had to be cast again."""
         if not self._pending:
             return False
@@ -418,8 +419,15 @@ class RayFan:
         if longest <= self._room * TILE and not log_full:
             return False
         self._force_exact = True
+        had_arrays, had_ends = list(self.G), [f for f in self.G_end if f not in self.G]
         self.G, self.G_end, self._post, self._host, self._scalars, self._ok_mask = {}, {}, None, {}, None, None
         self._cast(self._init_host, self.Cpt is not None)
+        # gains that were queued behind the provisional cast belonged to it: the same frequencies again, on the final one
+        # (a caller that holds on to fan.G[f] across validate() keeps finding it, now with every ray's full log behind it)
+        if had_arrays:
+            self.populate(*had_arrays)
+        if had_ends:
+            self.populate(*had_ends, keep_arrays=False)
         return True
 
     # -- scalars produced on demand ---------------------------------------------------------------

@@ -515,6 +515,29 @@ def test_gain_of_rays_with_thousands_of_rebounds(rt, orc):
     assert worst < 1e-10
 
 
+def test_gains_queued_behind_a_cast_that_is_done_again(rt):
+    """populate() may be queued behind a single-pass cast whose summary has not been read.  When that cast turns out to need
+    doing again (here: rebound logs beyond the provisional 64 entries) the gains are computed again on the final cast:
+    fan.G[f] is still there after validate() and equals the gains of a fan that was validated first."""
+    xs = np.linspace(0., 6000., 61)
+    env = rt.Environment2D((xs, np.full_like(xs, -10.)), (np.array([0., 6000.]), np.array([0., 0.])),
+                           np.array([0., -31.]), np.array([6000., 1.]))
+    angles = np.linspace(-1.3, -0.9, 40)
+    kw = dict(dx_max=10., dz_max=20., n_rebounds_max=-1, n_steps_max=2000)
+    first = rt.RayFan(env, np.array([0., -5.]), angles, **kw)
+    first.validate()
+    first.populate(1., 2500.)
+    late = rt.RayFan(env, np.array([0., -5.]), angles, **kw)
+    assert late._pending
+    late.populate(1., 2500.)
+    assert late.validate()                                   # cast again: the log overflowed
+    assert late.rebound_cap == first.rebound_cap > 64
+    for f in (1., 2500.):
+        assert np.array_equal(late.G_end[f].cpu().numpy(), first.G_end[f].cpu().numpy(), equal_nan=True)
+        for i in range(0, late.n, 7):
+            assert np.array_equal(late.ray_slice(late.G[f], i).cpu().numpy(), first.ray_slice(first.G[f], i).cpu().numpy(), equal_nan=True)
+
+
 def test_hint_bits_and_the_map_minor_scratch(rt):
     """Two helpers of the binning entry points through the C ABI.  rt2d_heatmap_hints (the hint bits of the ray mask in one
     launch) against the same conditions written with tensor operations; rt2d_heatmap_accumulate_multi with and without its
