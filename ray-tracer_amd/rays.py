@@ -691,8 +691,12 @@ class RayFan:
         with torch.cuda.device(self.device):
             sel = (self.status == 0) if ray_mask is None else ((self.status == 0) & (ray_mask != 0))
             mask = self.fused_mask(res, shape, ray_mask)
-            if self.__dict__.get('_exact_binning'):          # an earlier pass met a ray its binner could not take: every ray the stored way
-                mask = torch.zeros_like(mask)
+            # (an earlier pass met rays its binner could not take, and flagged them: those go the stored way this time -- the
+            # propagation is deterministic, so the others pass again as they did)
+            flagged = self.__dict__.get('_irregular')
+            if self.__dict__.get('_exact_binning'):
+                mask = mask & (flagged == 0).to(torch.uint8) if flagged is not None else torch.zeros_like(mask)
+            irr = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
             res_c = (C.c_int32 * 2)(int(res[0]), int(res[1]))
             shape_c = (C.c_int32 * 2)(int(shape[0]), int(shape[1]))
             src = (C.c_double * 2)(float(self.source[0]), float(self.source[1]))
@@ -713,7 +717,8 @@ class RayFan:
             before = torch.cuda.current_stream().record_event()
             rc = L.rt2d_cast_heatmap(handle, self.angles_dev.data_ptr(), self.n, src,
                                      C.byref(p), _ptr(self._init[0]), _ptr(self._init[1]), mask.data_ptr(), float(freq),
-                                     res_c, shape_c, 1.0, H.data_ptr(), None, None, viol.data_ptr(), _ptr(loss), cap, stream)
+                                     res_c, shape_c, 1.0, H.data_ptr(), None, irr.data_ptr(), viol.data_ptr(), _ptr(loss), cap, stream)
+            self._irregular = irr if flagged is None else (irr | flagged)
             if rc != 0:
                 # the fused kernel cannot take this environment (its tables do not fit in LDS) or these parameters
                 # (power_cutoff): every ray goes through the stored path, a chunk at a time

@@ -117,6 +117,9 @@ def test_a_ray_that_slips_through_the_mask_makes_the_map_start_over(rt, monkeypa
         assert int(((fan.monotone == 0) & (fan.status == 0)).sum().item()) > 0
         H = sim.heatmap_full(resolution=[50, 25], **extra)[0].cpu().numpy()
         assert fan.__dict__.get('_exact_binning') is True
+        if not store:                                     # (the second pass sends only the flagged rays the stored way)
+            n_flagged = int(fan._irregular.sum().item())
+            assert 0 < n_flagged == fan.last_slow_rays < fan.n // 2
         assert np.array_equal(H == 0, Hs == 0)
         assert (np.abs(H - Hs)[Hs != 0] / Hs[Hs != 0]).max() < 1e-12
 
