@@ -42,6 +42,23 @@ def main():
     sim = rt.Simulation2D(common.product_env(rt, g), g['fan_source'], distributed=True, shard='interleave')
     sim.cast(dup, sort=False, **common.prop_kwargs(g))
     out['dup_H'] = sim.heatmap_full(resolution=[50, 25])[0].cpu().numpy()
+    # a ray slips through the fused binner's mask on ONE rank (its mask is made to vouch for rays that turn back): the
+    # kernel counts it, the verdict is shared, and BOTH ranks bin again -- the same collectives in the same order on both
+    g = common.load('c2_fan999')
+    from ray_tracer_amd import rays as rays_mod
+    honest = rays_mod.RayFan.fused_mask
+    if rank == 1:
+        def vouch_for_all(self, res, shape, ray_mask=None):
+            ok = self.status == 0
+            if ray_mask is not None:
+                ok = ok & (ray_mask != 0)
+            return ok.to(torch.uint8)
+        rays_mod.RayFan.fused_mask = vouch_for_all
+    sim = rt.Simulation2D(common.product_env(rt, g), g['fan_source'], distributed=True, shard='interleave')
+    fan = sim.cast(g['fan_angles'], store=False, **common.prop_kwargs(g))
+    out['viol_H'] = sim.heatmap_full(resolution=[50, 25])[0].cpu().numpy()
+    out['viol_redone'] = np.int64(1 if fan.__dict__.get('_exact_binning') else 0)
+    rays_mod.RayFan.fused_mask = honest
     g = common.load('c5_eigen')
     sim = rt.EigenraySim2D(common.product_env(rt, g), g['source'], g['target'], int(g['n_rays']), int(g['n_rebounds_max']),
                            n_rays_scan=int(g['n_rays_scan']), scan_angle_min=float(g['scan_angle_min']),

@@ -47,6 +47,11 @@ def test_two_ranks_equal_one_process(rt, tmp_path):
     for r in range(2):
         assert got[r]['dup_H'].shape == Hd.shape and np.abs(got[r]['dup_H'] - Hd).max() <= 1e-12 * Hd.max()
 
+    # (one rank's fused binner met rays it could not take: both ranks started over, the map is the single-process one)
+    assert int(got[1]['viol_redone']) == 1 and int(got[0]['viol_redone']) == 0
+    for r in range(2):
+        assert got[r]['viol_H'].shape == H.shape and np.abs(got[r]['viol_H'] - H).max() <= 1e-12 * H.max()
+
     g = common.load('c5_eigen')
     assert int(got[0]['scan_n_local']) + int(got[1]['scan_n_local']) == int(g['n_rays_scan'])
     for r in range(2):
