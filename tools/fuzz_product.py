@@ -36,9 +36,15 @@ for seed in range(first, last):
         assert H.shape == Href.shape, (H.shape, Href.shape)
         assert int(dropped.item()) == drop_ref, (int(dropped.item()), drop_ref)
         assert np.array_equal(H == 0, Href == 0) and np.array_equal(np.isfinite(H), np.isfinite(Href)), 'occupancy'
-        m = np.isfinite(Href) & (Href != 0)
+        # (cells above 1e30 hold points whose 10^(G/10) is a SUBNORMAL double -- gains between -3000 and -3240 dB, ray.py:317
+        # evaluated as written: the two pows -- where one unit in the last place is 2^-32 relative and the device's pow and
+        # libm's may round differently: 2e-10 in 10^(G/10), 2e-11 in the value)
+        m = np.isfinite(Href) & (Href != 0) & (np.abs(Href) < 1e29)
         rel = float((np.abs(H - Href)[m] / np.abs(Href[m])).max(initial=0))
         assert rel < 1e-11, rel
+        m2 = np.isfinite(Href) & (np.abs(Href) >= 1e29)
+        rel2 = float((np.abs(H - Href)[m2] / np.abs(Href[m2])).max(initial=0))
+        assert rel2 < 1e-9, rel2
         assert out.shape == plot_ref.shape
         assert np.array_equal(np.isnan(out), np.isnan(plot_ref)), 'nan pattern of the normalised map'
         mm = ~np.isnan(plot_ref)
