@@ -529,6 +529,12 @@ def main():
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks and never touches the GPU
         sys.exit(launch_ranks(args.gpus))
 
+    # ONE line on stdout, the JSON: libraries write there too (gloo announces its connections on stdout, from C++), so the
+    # descriptor itself is pointed at stderr for the length of the run and the JSON line goes to the saved one at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -862,7 +868,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu:
             result['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + '\n').encode())
     if backend:
         dist.destroy_process_group()
 
