@@ -19,7 +19,8 @@ TOOLS = [('fuzz_bits.py', 900, 912),       # HIP vs oracle, bit for bit
          ('fuzz_packs.py', 100, 110),      # packs from overlapping unsorted casts
          ('fuzz_dist.py', 200, 216),       # distance to target: in the stepping kernel vs from stored trajectories
          ('fuzz_cutoff.py', 150, 160),     # power cut-off vs the oracle's rule
-         ('fuzz_eigen.py', 60, 68)]        # sweep selection, target products
+         ('fuzz_eigen.py', 60, 68),        # sweep selection, target products
+         ('fuzz_ranks.py', 400, 406)]      # two ranks on the one card (gloo) against one process
 
 
 @pytest.mark.parametrize('tool,first,last', TOOLS, ids=[t[0][:-3] for t in TOOLS])
